@@ -1,0 +1,392 @@
+"""ORACLE (test infrastructure, not product code).
+
+CPU restatement, in numpy, of the reference's window-scoring hot path (SURVEY.md §8a rows
+a-1 .. a-10).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module; the product (``dynamic-reward-rl-vae_amd/``) never does.
+
+Pinning status.  The arithmetic of the path lives in TensorFlow/Keras (unpinned third-party
+dependency; versions seen in the artefacts: TF 2.10/2.12/2.13, Keras 2.10.0/2.13.1), which is not
+installed here and cannot be fetched, and the reference has no tests.  The restatement is pinned by
+  * the env golden vectors produced by importing the reference's own ``env.py`` in the build
+    container (tests/golden/make_golden.py -> normalised series, states_list flag layout), and
+  * the soft known-answer test: greedy validation rollouts with the committed checkpoints
+    reproduce the committed ``exp/*performance.txt`` precision/recall/F1 (9/9 episodes for the
+    A2 LP200/AL100 run, 4/6 exactly + 2/6 within 2 predictions for A1 LP200/AL1000, whose
+    checkpoint pre-dates the last 10 Adam steps).  This pins gate order, forget_bias, the window /
+    flag layout, action feedback and the argmax convention.
+The VAE has no known answer in the reference (its ``predict`` is stochastic): "parity unpinned"
+for a-6/a-7 beyond Keras ``Dense`` semantics and the mean-path definition.
+
+Every function takes ``dtype`` so that the same code gives the fp32 restatement (numpy float32,
+what the reference computes in) and an fp64 variant used to judge rounding noise.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------- a-1 normalisation
+
+
+def minmax_f32(x):
+    """sklearn ``MinMaxScaler().fit_transform`` on a float32 column (reference env.py:75-79).
+
+    sklearn computes ``scale_ = 1/(max-min)``, ``min_ = 0 - min*scale_`` and ``x*scale_ + min_`` in
+    the column's dtype, float32 here because env.py casts (:75) before scaling (:78-79).  A zero
+    range is replaced by 1 (sklearn ``_handle_zeros_in_scale``).
+    """
+    x = np.asarray(x, dtype=np.float32)
+    mn, mx = x.min(), x.max()
+    rng = np.float32(mx - mn)
+    if rng == 0 or rng < 10 * np.finfo(np.float32).eps:
+        rng = np.float32(1.0)
+    scale = np.float32(1.0) / rng
+    off = np.float32(0.0) - mn * scale
+    return (x * scale + off).astype(np.float32), scale, off
+
+
+def minmax_f64_to_f32(x):
+    """reference env_smd.py:76-77, 97 — scale in float64, then cast the frame to float32."""
+    x = np.asarray(x, dtype=np.float64)
+    mn, mx = x.min(), x.max()
+    rng = mx - mn
+    if rng == 0 or rng < 10 * np.finfo(np.float64).eps:
+        rng = 1.0
+    scale = 1.0 / rng
+    off = 0.0 - mn * scale
+    return (x * scale + off).astype(np.float32), scale, off
+
+
+# ----------------------------------------------------------------------------- a-2 / a-3 states
+
+
+def states_list_univariate(v, W):
+    """``env.get_states_list()`` with ``statefnc = RNNBinaryStateFuc`` and ``curser_init = W``
+    (reference env.py:153-169, myasp-A1.py:120-134).
+
+    Window k (cursor c = k+W) holds values v[k+1 .. k+W].  The flag channel is all zero except the
+    single 1 the initial state carries in its last row (myasp-A1.py:126), which shifts up one row
+    per window: flag[k, W-1-k] = 1 for k < W.
+    Returns float32 (K, W, 2), K = N - W.
+    """
+    v = np.asarray(v, dtype=np.float32)
+    N = v.shape[0]
+    K = N - W
+    if K <= 0:
+        return np.zeros((0, W, 2), np.float32)
+    idx = np.arange(K)[:, None] + 1 + np.arange(W)[None, :]
+    out = np.zeros((K, W, 2), np.float32)
+    out[:, :, 0] = v[idx]
+    kk = np.arange(min(K, W))
+    out[kk, W - 1 - kk, 1] = 1.0
+    return out
+
+
+def states_list_univariate_literal(v, W):
+    """The same list built the way the reference builds it, one cursor at a time by shifting the
+    previous state (reference myasp-A1.py:120-134 driven by env.py:160-168).  Slow; used to check
+    the closed form above."""
+    v = np.asarray(v, dtype=np.float32)
+    N = v.shape[0]
+    states = []
+    for cursor in range(W, N):
+        if not states:
+            st = [[v[i], 0] for i in range(cursor)]
+            st.pop(0)
+            st.append([v[cursor], 1])
+            states.append(np.array(st, dtype=np.float32))
+        else:
+            prev = states[-1]
+            s0 = np.concatenate((prev[1:W], [[v[cursor], 0]]))
+            states.append(np.array(s0, dtype=np.float32))
+    return np.array(states, dtype=np.float32).reshape(-1, W, 2)
+
+
+def states_teacher_forced(v, W, actions):
+    """Rollout-mode states with a given action history.
+
+    ``actions[k]`` is the action taken at cursor k+W.  The state evaluated at cursor c = k+W has in
+    row t the flag of the action taken at cursor c-(W-1-t) ... but the *candidate* last row of the
+    state fed to the policy was fixed by the previous step: state_k = next_state[a_{k-1}], so row
+    W-1 carries a_{k-1} and row t carries a_{k-1-(W-1-t)}; the first state has flags
+    [0]*(W-1)+[1] (reference myasp-A1.py:122-127, env.py:143-147).
+    """
+    v = np.asarray(v, dtype=np.float32)
+    K = v.shape[0] - W
+    a = np.asarray(actions, dtype=np.float32)
+    # flag attached to sample index n (n >= W): 1 for n == W (initial state), else a[n-W-1]
+    fl = np.zeros(v.shape[0], np.float32)
+    if K > 0:
+        fl[W] = 1.0
+        fl[W + 1:W + K] = a[:K - 1]
+    idx = np.arange(K)[:, None] + 1 + np.arange(W)[None, :]
+    out = np.zeros((K, W, 2), np.float32)
+    out[:, :, 0] = v[idx]
+    out[:, :, 1] = fl[idx]
+    return out
+
+
+def make_state_multivariate(x, c, W):
+    """reference myasp-wadi.py:248-254: raw (unscaled) rows c-W+1..c plus a constant flag column,
+    stacked for flag 0 and flag 1 -> (2, W, F+1).  None for c < W."""
+    if c < W:
+        return None
+    x = np.asarray(x, dtype=np.float32)
+    Wd = x[c - W + 1:c + 1]
+    a0 = np.concatenate([Wd, np.zeros((W, 1), np.float32)], axis=1)
+    a1 = np.concatenate([Wd, np.ones((W, 1), np.float32)], axis=1)
+    return np.stack([a0, a1], axis=0)
+
+
+def states_multivariate(x, W, k0=0, k1=None):
+    """All candidate states for cursors c = k+W, k in [k0, k1) -> (K, 2, W, F+1)."""
+    x = np.asarray(x, dtype=np.float32)
+    N, F = x.shape
+    K = N - W
+    k1 = K if k1 is None else k1
+    idx = np.arange(k0, k1)[:, None] + 1 + np.arange(W)[None, :]
+    out = np.zeros((k1 - k0, 2, W, F + 1), np.float32)
+    out[:, 0, :, :F] = x[idx]
+    out[:, 1, :, :F] = x[idx]
+    out[:, 1, :, F] = 1.0
+    return out
+
+
+# ----------------------------------------------------------------------------- a-5 VAE windows
+
+
+def vae_windows_univariate(v, W):
+    """reference myasp-A1.py:139 — the reward at cursor c looks at v[c-W : c] (excludes v[c]).
+    Row k (cursor k+W) = v[k .. k+W-1]."""
+    v = np.asarray(v, dtype=np.float32)
+    K = v.shape[0] - W
+    idx = np.arange(K)[:, None] + np.arange(W)[None, :]
+    return v[idx]
+
+
+def vae_windows_multivariate(x, W, center=None, scale=None, clip=10.0, k0=0, k1=None):
+    """reference myasp-wadi.py:132-139 — windows i = W-1 .. N-1 of rows i-W+1..i, flattened
+    time-major (index t*F+f), RobustScaler ``(x-center_)/scale_`` per flattened column (float64
+    parameters applied to the float32 windows -> numpy promotes to float64), clip to +-clip.
+    The reference then feeds the float64 array to ``vae.predict`` which casts to float32.
+    Returns float32 (n, W*F); row j <-> window ending at sample j+W-1.
+    """
+    x = np.asarray(x, dtype=np.float32)
+    N, F = x.shape
+    n = N - W + 1
+    k1 = n if k1 is None else k1
+    idx = np.arange(k0, k1)[:, None] + np.arange(W)[None, :]
+    win = x[idx].reshape(k1 - k0, W * F)
+    if center is not None:
+        win = (win - np.asarray(center, np.float64)) / np.asarray(scale, np.float64)
+    if clip is not None:
+        win = np.clip(win, -clip, clip)
+    return win.astype(np.float32)
+
+
+def robust_scaler_fit(windows):
+    """sklearn ``RobustScaler().fit`` (reference myasp-wadi.py:96): center_ = median,
+    scale_ = IQR(25,75) with zeros replaced by 1; float64."""
+    w = np.asarray(windows, dtype=np.float64)
+    center = np.median(w, axis=0)
+    q = np.percentile(w, [25.0, 75.0], axis=0)
+    scale = q[1] - q[0]
+    scale[scale < 10 * np.finfo(np.float64).eps] = 1.0
+    return center, scale
+
+
+# ----------------------------------------------------------------------------- a-6 / a-7 VAE
+
+
+def _act(y, a):
+    if a == 1:
+        return np.maximum(y, 0)
+    if a == 2:
+        return 1.0 / (1.0 + np.exp(-y))
+    return y
+
+
+def vae_forward(x, kernels, biases, acts, mu_layer, logvar_layer, logvar_clip=10.0, eps=None,
+                dtype=np.float32):
+    """Keras functional VAE forward (reference myasp-A1.py:87-101, myasp-wadi.py:101-117).
+
+    Layers are ordered encoder hidden..., mu, logvar, decoder...; Keras ``Dense`` is
+    ``act(x @ kernel + bias)`` with kernel [in, out].  ``eps is None`` is the mean path z = mu
+    (BASELINE.json north_star); otherwise z = mu + exp(0.5*clip(logvar))*eps
+    (myasp-A1.py:84, 94).
+    """
+    h = np.asarray(x, dtype=dtype)
+    for l in range(mu_layer):
+        h = _act(h @ kernels[l].astype(dtype) + biases[l].astype(dtype), acts[l])
+    mu = _act(h @ kernels[mu_layer].astype(dtype) + biases[mu_layer].astype(dtype), acts[mu_layer])
+    z = mu
+    if eps is not None:
+        lv = h @ kernels[logvar_layer].astype(dtype) + biases[logvar_layer].astype(dtype)
+        if np.isfinite(logvar_clip):
+            lv = np.clip(lv, -logvar_clip, logvar_clip)
+        z = mu + np.exp(dtype(0.5) * lv) * np.asarray(eps, dtype=dtype)
+    h = z
+    for l in range(max(mu_layer, logvar_layer) + 1, len(kernels)):
+        h = _act(h @ kernels[l].astype(dtype) + biases[l].astype(dtype), acts[l])
+    return h
+
+
+def recon_error(x, recon, dtype=np.float32):
+    """reference myasp-A1.py:141 / myasp-wadi.py:146 — mean over the window of squared diff."""
+    x = np.asarray(x, dtype=dtype)
+    return np.mean(np.square(np.asarray(recon, dtype=dtype) - x), axis=-1)
+
+
+def reward_pair(err, label, coef, tn=1.0, tp=5.0, fp=-1.0, fn=-5.0):
+    """reference myasp-A1.py:143-151 — [r(action 0), r(action 1)] for one cursor."""
+    p = coef * err
+    if label == 0:
+        return [tn + p, fp + p]
+    if label == 1:
+        return [fn + p, tp + p]
+    return [0, 0]
+
+
+def penalty_array(recon_err, W):
+    """reference myasp-wadi.py:148-149 — W-1 zeros then the per-window errors."""
+    return np.concatenate([np.zeros(W - 1), np.asarray(recon_err)])
+
+
+# ----------------------------------------------------------------------------- a-8 LSTM-DQN
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def lstm_q(states, kernel, bias, w_out, b_out, forget_bias=1.0, dtype=np.float32):
+    """``static_rnn(LSTMCell(H, forget_bias=1.0))`` + linear head
+    (reference myasp-A1.py:176-179; myasp-wadi.py:220-224).
+
+    TF1 ``LSTMCell`` (no peepholes/projection): per step ``z = [x_t, h] @ kernel + bias``, gate
+    column blocks i | j | f | o, ``c = sigmoid(f + forget_bias)*c + sigmoid(i)*tanh(j)``,
+    ``h = sigmoid(o)*tanh(c)``; zero initial state.  states (B, W, I) -> Q (B, A).
+    """
+    s = np.asarray(states, dtype=dtype)
+    B, W, I = s.shape
+    H = kernel.shape[1] // 4
+    K = kernel.astype(dtype)
+    b = bias.astype(dtype)
+    h = np.zeros((B, H), dtype)
+    c = np.zeros((B, H), dtype)
+    fb = dtype(forget_bias)
+    for t in range(W):
+        z = np.concatenate([s[:, t, :], h], axis=1) @ K + b
+        i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+        c = _sigmoid(f + fb) * c + _sigmoid(i) * np.tanh(j)
+        h = _sigmoid(o) * np.tanh(c)
+    return h @ w_out.astype(dtype) + b_out.astype(dtype)
+
+
+# ----------------------------------------------------------------------------- a-9 / a-10
+
+
+def greedy_action(q):
+    """``np.argmax(q_values)`` with epsilon 0 (reference myasp-A1.py:226-227): ties -> 0."""
+    q = np.asarray(q)
+    return (q[..., 1] > q[..., 0]).astype(np.int32)
+
+
+def wadi_action(q_s0, q_s1):
+    """reference myasp-wadi.py:326-328 — a = 1 if Q(state a1)[1] > Q(state a0)[0] else 0."""
+    return (np.asarray(q_s1)[..., 1] > np.asarray(q_s0)[..., 0]).astype(np.int32)
+
+
+def al_margin(q):
+    """reference myasp-A1.py:254-255 — |q0 - q1| per window."""
+    q = np.asarray(q)
+    return np.abs(q[..., 0] - q[..., 1])
+
+
+def al_get_samples(q, n, already_selected=()):
+    """reference myasp-A1.py:250-259 — np.argsort of the margins (default quicksort, i.e. the
+    order numpy gives), minus already selected, first n."""
+    d = al_margin(q)
+    rank = np.argsort(d)
+    sel = set(int(i) for i in already_selected)
+    return [int(i) for i in rank if int(i) not in sel][:n]
+
+
+def rollout_greedy(v, W, kernel, bias, w_out, b_out, dtype=np.float32):
+    """``q_learning_validator`` inner loop (reference myasp-A1.py:471-496 with env.py:126-151):
+    start from the initial state (last flag 1), act greedily, feed the action back through the
+    flag channel of the next state.  Returns actions for cursors W .. N-1."""
+    v = np.asarray(v, dtype=np.float32)
+    N = v.shape[0]
+    state = np.array([[v[i], 0] for i in range(1, W)] + [[v[W], 1]], dtype=np.float32)
+    acts = []
+    for c in range(W, N):
+        q = lstm_q(state[None], kernel, bias, w_out, b_out, dtype=dtype)[0]
+        a = int(np.argmax(q))
+        acts.append(a)
+        if c + 1 < N:
+            state = np.concatenate((state[1:W], [[v[c + 1], a]])).astype(np.float32)
+    return np.array(acts, dtype=np.int32)
+
+
+def precision_recall_f1(truth, pred):
+    """sklearn ``precision_recall_fscore_support(average='binary')`` (reference
+    myasp-A1.py:498-500), zero_division -> 0."""
+    truth = np.asarray(truth).astype(int)
+    pred = np.asarray(pred).astype(int)
+    tp = int(np.sum((truth == 1) & (pred == 1)))
+    fp = int(np.sum((truth == 0) & (pred == 1)))
+    fn = int(np.sum((truth == 1) & (pred == 0)))
+    p = tp / (tp + fp) if tp + fp else 0.0
+    r = tp / (tp + fn) if tp + fn else 0.0
+    f = 2 * p * r / (p + r) if p + r else 0.0
+    return p, r, f
+
+
+# ----------------------------------------------------------------------------- whole path
+
+
+def score_series_univariate(v, W, vae, lstm, flag_mode="quirk", actions=None, dtype=np.float32):
+    """Everything the path produces for one normalised univariate series: per window k
+    (cursor k+W) the VAE mean-path reconstruction error of v[k..k+W-1], Q of the LSTM state
+    v[k+1..k+W] (+flags), greedy action, AL margin."""
+    X = vae_windows_univariate(v, W)
+    rec = vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"],
+                      vae["logvar_layer"], vae.get("logvar_clip", 10.0), dtype=dtype)
+    err = recon_error(X, rec, dtype=dtype)
+    if flag_mode == "quirk":
+        S = states_list_univariate(v, W)
+    elif flag_mode == "zeros":
+        S = states_list_univariate(v, W)
+        S[:, :, 1] = 0
+    elif flag_mode == "explicit":
+        S = states_teacher_forced(v, W, actions)
+    else:
+        raise ValueError(flag_mode)
+    q = lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"],
+               lstm.get("forget_bias", 1.0), dtype=dtype)
+    return {"err": err, "q": q, "action": greedy_action(q), "margin": al_margin(q)}
+
+
+def score_series_multivariate(x, W, vae, lstm, center=None, scale=None, clip=10.0,
+                              dtype=np.float32, chunk=4096):
+    """WaDi formulation (reference myasp-wadi.py:132-149, 248-254, 326-328) for cursors
+    c = W .. N-1 (window k = c - W): err = penalty_array[c] (window of rows c-W+1..c, scaled and
+    clipped), Q of both candidate states (raw values), action by the WaDi rule."""
+    x = np.asarray(x, dtype=np.float32)
+    N, F = x.shape
+    K = N - W
+    err = np.zeros(K, dtype)
+    q = np.zeros((K, 2, lstm["w_out"].shape[1]), dtype)
+    for k0 in range(0, K, chunk):
+        k1 = min(K, k0 + chunk)
+        # penalty_array[c] for c = k+W is the window ending at c: all_windows row c-(W-1) = k+1
+        X = vae_windows_multivariate(x, W, center, scale, clip, k0 + 1, k1 + 1)
+        rec = vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"],
+                          vae["logvar_layer"], vae.get("logvar_clip", 10.0), dtype=dtype)
+        err[k0:k1] = recon_error(X, rec, dtype=dtype)
+        S = states_multivariate(x, W, k0, k1)
+        qq = lstm_q(S.reshape(-1, W, F + 1), lstm["kernel"], lstm["bias"], lstm["w_out"],
+                    lstm["b_out"], lstm.get("forget_bias", 1.0), dtype=dtype)
+        q[k0:k1] = qq.reshape(k1 - k0, 2, -1)
+    return {"err": err, "q": q, "action": wadi_action(q[:, 0], q[:, 1]),
+            "margin": np.abs(q[:, 1, 1] - q[:, 0, 0])}

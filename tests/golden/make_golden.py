@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/ (run once in the build container, where
+/root/reference is mounted; the GPU box never runs this).
+
+What is taken from the reference itself:
+  * normalised series + anomaly labels: by importing the reference's own ``env.py``
+    (``EnvTimeSeriesfromRepo``) on the A1/A2 benchmark directories;
+  * ``states_list`` of real_1: ``env.get_states_list()`` driven by the reference's own
+    ``RNNBinaryStateFuc`` — the single FunctionDef is extracted from myasp-A1.py with ``ast`` and
+    exec'd with numpy in scope, because the module itself imports TensorFlow (absent) and trains
+    at import;
+  * trained weights: read from the reference's checkpoint bundles / ``vae_model.h5`` with this
+    repo's dependency-free readers (the files are data, loaded without executing anything);
+  * the soft known-answer numbers: the committed ``exp/*performance.txt`` lines.
+What is NOT from the reference: the expected err/Q/action vectors, which come from this repo's
+oracle (oracle/ref_path.py) and serve as regression anchors (TensorFlow cannot run here).
+"""
+import ast
+import io
+import json
+import os
+import re
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "dynamic-reward-rl-vae_amd"))
+sys.path.insert(0, REF)
+
+from drlvae.formats.tf_bundle import TFBundle, load_q_estimator, load_vae_dense_chain  # noqa: E402
+from drlvae.formats.keras_h5 import load_keras_vae  # noqa: E402
+from oracle import ref_path as orc  # noqa: E402
+
+import env as ref_env  # noqa: E402  (the reference's env.py)
+
+YDIR = os.path.join(REF, "ydata-labeled-time-series-anomalies-v1_0")
+A1_RUN = "A1_LP_1500init_warmup_h128_b256_300ep_num_LP200_num_AL1000_d0.96"
+A2_RUN = "A2_LP_1500init_warmup_h128_b256_300ep_num_LP200_num_AL100_d0.96"
+
+
+def load_repo(subdir):
+    with redirect_stdout(io.StringIO()):
+        e = ref_env.EnvTimeSeriesfromRepo(os.path.join(YDIR, subdir))
+    order = sorted(range(len(e.repodirext)), key=lambda i: os.path.basename(e.repodirext[i]))
+    names = [os.path.basename(e.repodirext[i]) for i in order]
+    series = [e.timeseries_repo[i]["value"].values.astype(np.float32) for i in order]
+    anomaly = [e.timeseries_repo[i]["anomaly"].values.astype(np.uint8) for i in order]
+    return e, names, series, anomaly
+
+
+def pack(series):
+    off = np.zeros(len(series) + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in series])
+    return np.concatenate(series), off
+
+
+def extract_function(path, name):
+    src = open(path, encoding="utf-8").read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            return ast.get_source_segment(src, node)
+    raise KeyError(name)
+
+
+def parse_perf(path):
+    out = []
+    for line in open(path):
+        m = re.search(r"Precision:([^,]+), Recall:([^,]+), F1-score:(\S+)", line)
+        out.append([float(m.group(1)), float(m.group(2)), float(m.group(3))])
+    return out
+
+
+def vae_from_chain(chain):
+    n = len(chain)
+    # hidden..., mu, logvar, dec hidden, out (reference myasp-A1.py:89-99)
+    mu = n - 4
+    acts = [1] * mu + [0, 0, 1, 2]
+    return {"kernels": [k for k, _ in chain], "biases": [b for _, b in chain], "acts": acts,
+            "mu_layer": mu, "logvar_layer": mu + 1, "logvar_clip": 10.0}
+
+
+def save_model_npz(path, lstm, vae):
+    d = {f"lstm_{k}": v for k, v in lstm.items()}
+    if vae is not None:
+        for i, (k, b) in enumerate(zip(vae["kernels"], vae["biases"])):
+            d[f"vae_k{i}"] = k
+            d[f"vae_b{i}"] = b
+        d["vae_acts"] = np.array(vae["acts"], np.int32)
+        d["vae_mu_layer"] = np.int32(vae["mu_layer"])
+        d["vae_logvar_layer"] = np.int32(vae["logvar_layer"])
+        d["vae_logvar_clip"] = np.float32(vae["logvar_clip"])
+    np.savez_compressed(path, **d)
+
+
+def main():
+    # ---- A1: all 67 normalised series (reference env.py), lexicographic order
+    e1, names1, series1, anom1 = load_repo("A1Benchmark")
+    flat, off = pack(series1)
+    aflat, _ = pack(anom1)
+    # raw float32 values of the first three files, to test the device-side MinMax (a-1)
+    import pandas as pd
+    raw = [pd.read_csv(os.path.join(YDIR, "A1Benchmark", n), usecols=[1]).values[:, 0].astype(np.float32)
+           for n in names1[:3]]
+    rflat, roff = pack(raw)
+    np.savez_compressed(os.path.join(HERE, "a1_series.npz"), values=flat, offsets=off,
+                        anomaly=aflat, names=np.array(names1), raw3=rflat, raw3_offsets=roff)
+    # oracle normalisation must be bit-identical to sklearn's
+    for n, r, s in zip(names1[:3], raw, series1[:3]):
+        mine, _, _ = orc.minmax_f32(r)
+        assert np.array_equal(mine.view(np.uint32), s.view(np.uint32)), n
+
+    # ---- states_list of real_1 by the reference's own state function
+    W = 25
+    ns = {"np": np, "n_steps": W}
+    exec(extract_function(os.path.join(REF, "myasp-A1.py"), "RNNBinaryStateFuc"), ns)
+    e1.statefnc = ns["RNNBinaryStateFuc"]
+    e1.timeseries_curser_init = W
+    e1.datasetidx = [os.path.basename(p) for p in e1.repodirext].index("real_1.csv")
+    sl = np.array(e1.get_states_list(), dtype=np.float32)
+    assert sl.shape == (len(series1[0]) - W, W, 2)
+    assert np.array_equal(sl, orc.states_list_univariate(series1[0], W))
+    assert np.array_equal(sl, orc.states_list_univariate_literal(series1[0], W))
+    np.savez_compressed(os.path.join(HERE, "states_list_real_1.npz"), states=sl)
+
+    # ---- A2 validation series (#90..98 lexicographic)
+    _, names2, series2, anom2 = load_repo("A2Benchmark")
+    lo = int(len(names2) * 0.9)
+    f2, o2 = pack(series2[lo:lo + 9])
+    a2, _ = pack(anom2[lo:lo + 9])
+    np.savez_compressed(os.path.join(HERE, "a2_val_series.npz"), values=f2, offsets=o2, anomaly=a2,
+                        names=np.array(names2[lo:lo + 9]))
+
+    # ---- weights
+    models = {}
+    for tag, run in (("a1", A1_RUN), ("a2", A2_RUN)):
+        prefix = os.path.join(REF, "exp", run, "checkpoints", "model")
+        lstm = load_q_estimator(prefix, "qlearn")
+        b = TFBundle(prefix)
+        for nm in ("qlearn/rnn/lstm_cell/kernel", "qlearn/rnn/lstm_cell/bias"):
+            b.get(nm, verify_crc=True)
+        chain = load_vae_dense_chain(prefix)
+        vae = vae_from_chain(chain)
+        save_model_npz(os.path.join(HERE, f"ckpt_{tag}.npz"), lstm, vae)
+        models[tag] = (lstm, vae, int(b.get("global_step")))
+    h5 = load_keras_vae(os.path.join(REF, "vae_model.h5"))
+    save_model_npz(os.path.join(HERE, "vae_model_h5.npz"), {}, h5)
+
+    # ---- soft KAT: committed performance files
+    kat = {
+        "a1": {"run": A1_RUN, "global_step": models["a1"][2],
+               # validator skips while idx < n*0.9 (reference myasp-A1.py:473) -> first idx 61
+               "files": names1[int(np.ceil(len(names1) * 0.9)):][:6],
+               "first_index": int(np.ceil(len(names1) * 0.9)),
+               "perf": parse_perf(os.path.join(REF, "exp", A1_RUN + "performance.txt"))},
+        "a2": {"run": A2_RUN, "global_step": models["a2"][2],
+               "files": names2[lo:lo + 9], "first_index": lo,
+               "perf": parse_perf(os.path.join(REF, "exp", A2_RUN + "performance.txt"))},
+    }
+    json.dump(kat, open(os.path.join(HERE, "soft_kat.json"), "w"), indent=1)
+
+    # ---- oracle regression anchors on real_1 (C1), fp32 and fp64
+    lstm, vae, _ = models["a1"]
+    out = {}
+    for nm, dt in (("f32", np.float32), ("f64", np.float64)):
+        r = orc.score_series_univariate(series1[0], W, vae, lstm, "quirk", dtype=dt)
+        out[f"err_{nm}"] = r["err"]
+        out[f"q_{nm}"] = r["q"]
+        out[f"action_{nm}"] = r["action"]
+        rz = orc.score_series_univariate(series1[0], W, vae, lstm, "zeros", dtype=dt)
+        out[f"q_zeros_{nm}"] = rz["q"]
+    X = orc.vae_windows_univariate(series1[0], W)
+    rec = orc.vae_forward(X, h5["kernels"], h5["biases"], h5["acts"], h5["mu_layer"],
+                          h5["logvar_layer"], h5["logvar_clip"], dtype=np.float64)
+    out["err_h5_f64"] = orc.recon_error(X, rec, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "c1_expected.npz"), **out)
+    print("err f32 min/mean/max", out["err_f32"].min(), out["err_f32"].mean(), out["err_f32"].max())
+    print("q zeros[0:3]", out["q_zeros_f32"][:3], "actions==1:", int(out["action_f32"].sum()))
+    print("fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

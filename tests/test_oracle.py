@@ -1,0 +1,101 @@
+"""The oracle against the reference-derived fixtures (CPU only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_model_npz, split_series
+from oracle import ref_path as orc
+
+W = 25
+
+
+def test_minmax_bit_exact_vs_reference_env(a1):
+    # fixture values were produced by the reference's env.py (sklearn MinMaxScaler on float32)
+    for raw, want in zip(a1["raw3"], a1["series"][:3]):
+        got, _, _ = orc.minmax_f32(raw)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_states_list_matches_reference_state_function(a1):
+    want = np.load(os.path.join(GOLDEN, "states_list_real_1.npz"))["states"]
+    got = orc.states_list_univariate(a1["series"][0], W)
+    assert got.shape == want.shape == (1395, W, 2)
+    assert np.array_equal(got, want)
+    assert int(want[:, :, 1].sum()) == 25          # the flag quirk: 25 ones in total
+    assert np.array_equal(orc.states_list_univariate_literal(a1["series"][0][:80], W),
+                          orc.states_list_univariate(a1["series"][0][:80], W))
+
+
+def test_teacher_forced_states_reproduce_rollout(a1, ckpt_a1):
+    lstm, _ = ckpt_a1
+    v = a1["series"][65][:120]
+    acts = orc.rollout_greedy(v, W, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"])
+    S = orc.states_teacher_forced(v, W, acts)
+    q = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"])
+    assert np.array_equal(orc.greedy_action(q), acts)
+
+
+def _rollout_prf(series, anomaly, lstm):
+    acts = orc.rollout_greedy(series, W, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"])
+    return orc.precision_recall_f1(anomaly[W:], acts), int(acts.sum())
+
+
+def test_soft_kat_a2_all_nine_episodes(ckpt_a2):
+    """Greedy validation rollouts with the committed A2 checkpoint reproduce the reference's own
+    exp/A2_...LP200_num_AL100_d0.96performance.txt (all nine lines)."""
+    kat = json.load(open(os.path.join(GOLDEN, "soft_kat.json")))["a2"]
+    z = np.load(os.path.join(GOLDEN, "a2_val_series.npz"))
+    series = split_series(z)
+    off = z["offsets"]
+    lstm, _ = ckpt_a2
+    for i, (s, want) in enumerate(zip(series, kat["perf"])):
+        (p, r, f), _ = _rollout_prf(s, z["anomaly"][off[i]:off[i + 1]], lstm)
+        assert (p, r, f) == pytest.approx(tuple(want), abs=1e-9), (i, p, r, f, want)
+
+
+def test_soft_kat_a1(a1, ckpt_a1):
+    """A1 LP200/AL1000: episodes 1,3,5,6 exact; 2 and 4 within two predicted positives (the
+    checkpoint pre-dates the last 10 Adam steps, reference myasp-A1.py:380-382)."""
+    kat = json.load(open(os.path.join(GOLDEN, "soft_kat.json")))["a1"]
+    lstm, _ = ckpt_a1
+    exact = 0
+    for j, want in enumerate(kat["perf"]):
+        idx = kat["first_index"] + j
+        assert a1["names"][idx] == kat["files"][j]
+        truth = a1["anomaly"][idx]
+        (p, r, f), npos = _rollout_prf(a1["series"][idx], truth, lstm)
+        if (p, r, f) == pytest.approx(tuple(want), abs=1e-9):
+            exact += 1
+        else:
+            # recover the reference's predicted-positive count from its precision/recall
+            tp_ref = round(want[1] * int(truth[W:].sum()))
+            npos_ref = round(tp_ref / want[0]) if want[0] else 0
+            assert abs(npos - npos_ref) <= 2, (j, npos, npos_ref)
+    assert exact >= 4
+
+
+def test_c1_regression_anchors(a1, ckpt_a1):
+    lstm, vae = ckpt_a1
+    exp = np.load(os.path.join(GOLDEN, "c1_expected.npz"))
+    r = orc.score_series_univariate(a1["series"][0], W, vae, lstm, "quirk")
+    np.testing.assert_allclose(r["err"], exp["err_f32"], rtol=1e-6)
+    np.testing.assert_allclose(r["q"], exp["q_f32"], rtol=1e-6)
+    # fp32 restatement vs fp64 restatement: rounding noise is far below the 1e-5 tolerance
+    np.testing.assert_allclose(exp["err_f32"], exp["err_f64"], rtol=2e-6)
+    np.testing.assert_allclose(exp["q_f32"], exp["q_f64"], rtol=2e-6)
+    assert np.array_equal(exp["action_f32"], exp["action_f64"])
+
+
+def test_multivariate_alignment():
+    rng = np.random.default_rng(0)
+    x = rng.random((60, 3), dtype=np.float32)
+    st = orc.states_multivariate(x, W)
+    for c in (25, 40, 59):
+        np.testing.assert_array_equal(st[c - W], orc.make_state_multivariate(x, c, W))
+    win = orc.vae_windows_multivariate(x, W, None, None, None)
+    assert win.shape == (36, 75)
+    np.testing.assert_array_equal(win[5], x[5:30].reshape(-1))
+    pen = orc.penalty_array(np.arange(36), W)
+    assert len(pen) == 60 and pen[23] == 0 and pen[24] == 0 and pen[25] == 1
