@@ -1,0 +1,770 @@
+// libdrlvae: C-ABI (include/drlvae.h) over the CDNA4 kernels in kernels.hip.h.
+// Host side: weight re-packing into MFMA fragment order, series segment tables, launches.
+#include "../../include/drlvae.h"
+#include "kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct VaeHost {
+    bool set = false;
+    int n_path = 0;                       // layers on the mean path
+    int din[DRL_MAX_VAE_LAYERS], dout[DRL_MAX_VAE_LAYERS], act[DRL_MAX_VAE_LAYERS];
+    size_t w_off[DRL_MAX_VAE_LAYERS], b_off[DRL_MAX_VAE_LAYERS];   // float offsets in the pack
+    int mu_idx = 0;
+    size_t wlv_off = 0, blv_off = 0;
+    bool has_lv = false;
+    float lv_clip = 0;
+    int latent = 0;
+    int D = 0;                            // input width
+};
+
+struct LstmHost {
+    bool set = false;
+    int I = 0, H = 0, A = 0, NT = 0;
+    float forget_bias = 1.0f;
+    size_t wx_off = 0, u_off = 0, bias_off = 0, wout_off = 0, bout_off = 0;
+};
+
+struct Prof {
+    bool on = false;
+    struct Pair { hipEvent_t a, b; int which; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[2] = {0, 0};
+    int64_t n[2] = {0, 0};
+};
+
+}  // namespace
+
+struct drl_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    VaeHost vae;
+    LstmHost lstm;
+    DevBuf vae_w, lstm_w;       // packed weights
+    DevBuf seg;                 // segment tables
+    DevBuf opt;                 // per-series / per-column option arrays
+    DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
+    void* pinned = nullptr;     // pinned host staging for the segment tables
+    size_t pinned_cap = 0;
+    Prof prof;
+    const char* last_variant = "none";
+    // the segment tables of the last call stay valid on the device while the same series layout is scored again
+    std::vector<int64_t> seg_key;
+    long long seg_K = 0;
+    int seg_t32 = 0, seg_t64 = 0;
+};
+
+namespace {
+
+int fail(drl_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), DRL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+int ensure(drl_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return DRL_OK;
+    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t cap = std::max<size_t>(bytes, 256);
+    HIP_TRY(c, hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return DRL_OK;
+}
+
+int ensure_pinned(drl_ctx* c, size_t bytes) {
+    if (bytes <= c->pinned_cap) return DRL_OK;
+    if (c->pinned) { HIP_TRY(c, hipHostFree(c->pinned)); c->pinned = nullptr; c->pinned_cap = 0; }
+    size_t cap = std::max<size_t>(bytes * 2, 4096);
+    HIP_TRY(c, hipHostMalloc(&c->pinned, cap, hipHostMallocDefault));
+    c->pinned_cap = cap;
+    return DRL_OK;
+}
+
+inline int rowmap_h(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+inline size_t up16(size_t n) { return (n + 15) & ~size_t(15); }
+
+// Dense layer K [din,dout] -> A fragments [out_tile][in_tile][16][64]:
+// lane l of k-step r holds K[in = it*32 + rowmap(r, l>>5)][out = ot*32 + (l&31)] (0 outside).
+void pack_dense(const float* K, int din, int dout, float* dst) {
+    const int nin = (din + 31) / 32, nout = (dout + 31) / 32;
+    for (int ot = 0; ot < nout; ++ot)
+        for (int it = 0; it < nin; ++it)
+            for (int r = 0; r < 16; ++r)
+                for (int l = 0; l < 64; ++l) {
+                    const int in = it * 32 + rowmap_h(r, l >> 5), out = ot * 32 + (l & 31);
+                    dst[(((size_t)ot * nin + it) * 16 + r) * 64 + l] =
+                        (in < din && out < dout) ? K[(size_t)in * dout + out] : 0.0f;
+                }
+}
+// bias [dout] -> [out_tile][2][16]: entry (ot, half, r) = bias[ot*32 + rowmap(r, half)]
+void pack_bias(const float* b, int dout, float* dst) {
+    const int nout = (dout + 31) / 32;
+    for (int ot = 0; ot < nout; ++ot)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r) {
+                const int o = ot * 32 + rowmap_h(r, half);
+                dst[(ot * 2 + half) * 16 + r] = o < dout ? b[o] : 0.0f;
+            }
+}
+
+void prof_begin(drl_ctx* c, int which) {
+    if (!c->prof.on) return;
+    Prof::Pair p;
+    for (hipEvent_t* e : {&p.a, &p.b}) {
+        if (!c->prof.pool.empty()) { *e = c->prof.pool.back(); c->prof.pool.pop_back(); }
+        else if (hipEventCreate(e) != hipSuccess) { *e = nullptr; }
+    }
+    p.which = which;
+    if (p.a) (void)hipEventRecord(p.a, c->stream);
+    c->prof.pending.push_back(p);
+}
+void prof_end(drl_ctx* c) {
+    if (!c->prof.on || c->prof.pending.empty()) return;
+    Prof::Pair& p = c->prof.pending.back();
+    if (p.b) (void)hipEventRecord(p.b, c->stream);
+}
+int prof_collect(drl_ctx* c) {
+    for (auto& p : c->prof.pending) {
+        if (p.a && p.b) {
+            HIP_TRY(c, hipEventSynchronize(p.b));
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
+            c->prof.ms[p.which] += ms;
+            c->prof.n[p.which] += 1;
+        }
+        if (p.a) c->prof.pool.push_back(p.a);
+        if (p.b) c->prof.pool.push_back(p.b);
+    }
+    c->prof.pending.clear();
+    return DRL_OK;
+}
+
+struct SegHost {
+    long long K_total = 0;
+    int tiles32 = 0, tiles64 = 0;
+    // device pointers into ctx->seg
+    const long long* d_samp = nullptr;
+    const long long* d_win = nullptr;
+    const int* d_t32 = nullptr;
+    const int* d_t64 = nullptr;
+};
+
+// Builds and uploads the per-series tables.  n_win[i] = windows of series i.
+int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, bool windows_are_rows,
+                   SegHost& out) {
+    const size_t n1 = (size_t)n_seg + 1;
+    const size_t bytes = n1 * (2 * sizeof(long long) + 2 * sizeof(int));
+    std::vector<int64_t> key(seg_offsets, seg_offsets + n1);
+    key.push_back(W);
+    key.push_back(windows_are_rows ? 1 : 0);
+    if (key == c->seg_key && c->seg.p) {
+        out.K_total = c->seg_K; out.tiles32 = c->seg_t32; out.tiles64 = c->seg_t64;
+        out.d_samp = (const long long*)c->seg.p;
+        out.d_win = out.d_samp + n1;
+        out.d_t32 = (const int*)(out.d_win + n1);
+        out.d_t64 = out.d_t32 + n1;
+        return DRL_OK;
+    }
+    c->seg_key.clear();
+    int rc = ensure_pinned(c, bytes);
+    if (rc) return rc;
+    rc = ensure(c, c->seg, bytes);
+    if (rc) return rc;
+    // the previous call's async copy out of the pinned buffer must be done before it is rewritten
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    long long* samp = (long long*)c->pinned;
+    long long* win = samp + n1;
+    int* t32 = (int*)(win + n1);
+    int* t64 = t32 + n1;
+    long long wacc = 0, a32 = 0, a64 = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        const long long N = seg_offsets[i + 1] - seg_offsets[i];
+        if (N < 0) return fail(c, DRL_ERR_ARG, "seg_offsets must be non-decreasing (series %d)", i);
+        const long long K = windows_are_rows ? N : std::max<long long>(0, N - W);
+        samp[i] = seg_offsets[i];
+        win[i] = wacc;
+        t32[i] = (int)a32;
+        t64[i] = (int)a64;
+        wacc += K;
+        a32 += (K + 31) / 32;
+        a64 += (K + 63) / 64;
+        if (a32 > 0x7fffffffLL) return fail(c, DRL_ERR_ARG, "too many windows for one call");
+    }
+    samp[n_seg] = seg_offsets[n_seg];
+    win[n_seg] = wacc;
+    t32[n_seg] = (int)a32;
+    t64[n_seg] = (int)a64;
+    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    out.K_total = wacc;
+    out.tiles32 = (int)a32;
+    out.tiles64 = (int)a64;
+    out.d_samp = (const long long*)c->seg.p;
+    out.d_win = out.d_samp + n1;
+    out.d_t32 = (const int*)(out.d_win + n1);
+    out.d_t64 = out.d_t32 + n1;
+    c->seg_key = key; c->seg_K = wacc; c->seg_t32 = out.tiles32; c->seg_t64 = out.tiles64;
+    return DRL_OK;
+}
+
+void fill_vae_args(drl_ctx* c, VaeArgs& a) {
+    const VaeHost& v = c->vae;
+    const float* base = (const float*)c->vae_w.p;
+    a.n = v.n_path;
+    for (int p = 0; p < v.n_path; ++p) {
+        a.din[p] = v.din[p]; a.dout[p] = v.dout[p]; a.act[p] = v.act[p];
+        a.w[p] = base + v.w_off[p];
+        a.b[p] = base + v.b_off[p];
+    }
+    a.mu_idx = v.mu_idx;
+    a.w_lv = v.has_lv ? base + v.wlv_off : nullptr;
+    a.b_lv = v.has_lv ? base + v.blv_off : nullptr;
+    a.lv_clip = v.lv_clip;
+}
+
+void fill_lstm_args(drl_ctx* c, LstmArgs& a) {
+    const LstmHost& l = c->lstm;
+    const float* base = (const float*)c->lstm_w.p;
+    a.I = l.I; a.H = l.H; a.A = l.A;
+    a.forget_bias = l.forget_bias;
+    a.wx = base + l.wx_off;
+    a.u = base + l.u_off;
+    a.bias = base + l.bias_off;
+    a.w_out = base + l.wout_off;
+    a.b_out = base + l.bout_off;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* drl_version(void) { return "drlvae 0.1 (gfx950)"; }
+
+int drl_create(int device_id, drl_ctx** out) {
+    if (!out) return fail(nullptr, DRL_ERR_ARG, "drl_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, DRL_ERR_HIP, "drl_create: no HIP device (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, DRL_ERR_ARG, "drl_create: device %d out of range (0..%d)", device_id, n - 1);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail(nullptr, DRL_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, DRL_ERR_HIP, "drl_create: device %d is %s; the kernels are built for gfx950 only",
+                    device_id, prop.gcnArchName);
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, DRL_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    drl_ctx* c = new drl_ctx();
+    c->device = device_id;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, DRL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return DRL_OK;
+}
+
+void drl_destroy(drl_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof.pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+    for (auto e : c->prof.pool) (void)hipEventDestroy(e);
+    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->st_in, &c->st_flags, &c->st_eps,
+                      &c->st_err, &c->st_q, &c->st_act, &c->st_margin})
+        if (b->p) (void)hipFree(b->p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* drl_last_error(drl_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int drl_set_stream(drl_ctx* c, void* s) {
+    if (!c) return DRL_ERR_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return DRL_OK;
+}
+
+int drl_synchronize(drl_ctx* c) {
+    if (!c) return DRL_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DRL_OK;
+}
+
+int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t* out_dims,
+                const int32_t* acts, int mu_layer, int logvar_layer,
+                const float* const* kernels, const float* const* biases, float logvar_clip) {
+    if (!c) return DRL_ERR_ARG;
+    if (!in_dims || !out_dims || !acts || !kernels || !biases)
+        return fail(c, DRL_ERR_ARG, "drl_set_vae: null argument");
+    if (n_layers < 2 || n_layers > DRL_MAX_VAE_LAYERS + 1)
+        return fail(c, DRL_ERR_ARG, "drl_set_vae: n_layers %d out of range", n_layers);
+    if (mu_layer < 0 || mu_layer >= n_layers - 1)
+        return fail(c, DRL_ERR_ARG, "drl_set_vae: mu_layer %d out of range", mu_layer);
+    if (logvar_layer >= n_layers || logvar_layer == mu_layer)
+        return fail(c, DRL_ERR_ARG, "drl_set_vae: bad logvar_layer %d", logvar_layer);
+    for (int l = 0; l < n_layers; ++l) {
+        if (in_dims[l] < 1 || out_dims[l] < 1 || !kernels[l] || !biases[l])
+            return fail(c, DRL_ERR_ARG, "drl_set_vae: layer %d has bad dims or null weights", l);
+        if (acts[l] < 0 || acts[l] > 2) return fail(c, DRL_ERR_ARG, "drl_set_vae: layer %d activation %d", l, acts[l]);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    VaeHost v;
+    std::vector<int> path;
+    for (int l = 0; l < n_layers; ++l) if (l != logvar_layer) path.push_back(l);
+    v.n_path = (int)path.size();
+    if (v.n_path < 2 || v.n_path > DRL_MAX_VAE_LAYERS)
+        return fail(c, DRL_ERR_UNSUPPORTED, "drl_set_vae: %d layers on the mean path (2..%d supported)", v.n_path,
+                    DRL_MAX_VAE_LAYERS);
+    size_t off = 0;
+    for (int p = 0; p < v.n_path; ++p) {
+        const int l = path[p];
+        v.din[p] = in_dims[l]; v.dout[p] = out_dims[l]; v.act[p] = acts[l];
+        if (l == mu_layer) v.mu_idx = p;
+        if (p > 0 && v.din[p] != v.dout[p - 1])
+            return fail(c, DRL_ERR_ARG, "drl_set_vae: layer %d input %d != previous output %d", l, v.din[p], v.dout[p - 1]);
+        if (p < v.n_path - 1 && v.dout[p] > 32 * DRL_VAE_MAX_TILES)
+            return fail(c, DRL_ERR_UNSUPPORTED, "drl_set_vae: hidden width %d > %d", v.dout[p], 32 * DRL_VAE_MAX_TILES);
+        const size_t nin = (v.din[p] + 31) / 32, nout = (v.dout[p] + 31) / 32;
+        v.w_off[p] = off; off += nin * nout * 1024;
+        v.b_off[p] = off; off += up16(nout * 32);
+    }
+    v.D = v.din[0];
+    if (v.dout[v.n_path - 1] != v.D)
+        return fail(c, DRL_ERR_ARG, "drl_set_vae: output width %d != input width %d", v.dout[v.n_path - 1], v.D);
+    v.latent = out_dims[mu_layer];
+    v.has_lv = logvar_layer >= 0;
+    if (v.has_lv) {
+        if (in_dims[logvar_layer] != in_dims[mu_layer] || out_dims[logvar_layer] != v.latent)
+            return fail(c, DRL_ERR_ARG, "drl_set_vae: logvar layer shape differs from mu layer");
+        const size_t nin = (in_dims[logvar_layer] + 31) / 32, nout = (v.latent + 31) / 32;
+        v.wlv_off = off; off += nin * nout * 1024;
+        v.blv_off = off; off += up16(nout * 32);
+    }
+    v.lv_clip = std::isfinite(logvar_clip) ? logvar_clip : 0.0f;
+    std::vector<float> pack(off, 0.0f);
+    for (int p = 0; p < v.n_path; ++p) {
+        const int l = path[p];
+        pack_dense(kernels[l], v.din[p], v.dout[p], pack.data() + v.w_off[p]);
+        pack_bias(biases[l], v.dout[p], pack.data() + v.b_off[p]);
+    }
+    if (v.has_lv) {
+        pack_dense(kernels[logvar_layer], in_dims[logvar_layer], v.latent, pack.data() + v.wlv_off);
+        pack_bias(biases[logvar_layer], v.latent, pack.data() + v.blv_off);
+    }
+    int rc = ensure(c, c->vae_w, off * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->vae_w.p, pack.data(), off * sizeof(float), hipMemcpyHostToDevice));
+    v.set = true;
+    c->vae = v;
+    return DRL_OK;
+}
+
+int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget_bias,
+                 const float* kernel, const float* bias, const float* w_out, const float* b_out) {
+    if (!c) return DRL_ERR_ARG;
+    if (!kernel || !bias || !w_out || !b_out) return fail(c, DRL_ERR_ARG, "drl_set_lstm: null argument");
+    if (in_dim < 1 || n_actions < 2 || n_actions > 8)
+        return fail(c, DRL_ERR_ARG, "drl_set_lstm: in_dim %d / n_actions %d out of range", in_dim, n_actions);
+    if (hidden < 8 || hidden > 128 || hidden % 8)
+        return fail(c, DRL_ERR_UNSUPPORTED, "drl_set_lstm: hidden %d (multiples of 8 up to 128 supported)", hidden);
+    HIP_TRY(c, hipSetDevice(c->device));
+    LstmHost l;
+    l.I = in_dim; l.H = hidden; l.A = n_actions; l.forget_bias = forget_bias;
+    l.NT = hidden <= 64 ? 8 : 16;                       // kernel template: gate tiles, padded
+    const int NT = l.NT, H = hidden, nks = (in_dim + 1) / 2;
+    size_t off = 0;
+    l.wx_off = off; off += (size_t)nks * NT * 64;
+    l.u_off = off; off += (size_t)(NT * 4) * NT * 64;
+    l.bias_off = off; off += (size_t)NT * 32;
+    l.wout_off = off; off += up16((size_t)NT * 8 * n_actions);
+    l.bout_off = off; off += 16;
+    std::vector<float> pack(off, 0.0f);
+    // gate-interleaved rows: row i of tile tau = (unit 8*tau + (i>>2), gate i&3) -> TF column gate*H + unit
+    auto col = [&](int tau, int i) -> int {
+        const int unit = 8 * tau + (i >> 2), gate = i & 3;
+        return unit < H ? gate * H + unit : -1;
+    };
+    const size_t ld = 4 * (size_t)H;
+    for (int ks = 0; ks < nks; ++ks)
+        for (int tau = 0; tau < NT; ++tau)
+            for (int ln = 0; ln < 64; ++ln) {
+                const int feat = 2 * ks + (ln >> 5), cc = col(tau, ln & 31);
+                pack[l.wx_off + ((size_t)ks * NT + tau) * 64 + ln] =
+                    (feat < in_dim && cc >= 0) ? kernel[(size_t)feat * ld + cc] : 0.0f;
+            }
+    for (int kk = 0; kk < NT * 4; ++kk)
+        for (int tau = 0; tau < NT; ++tau)
+            for (int ln = 0; ln < 64; ++ln) {
+                const int unit = 8 * (kk >> 2) + 2 * (kk & 3) + (ln >> 5), cc = col(tau, ln & 31);
+                pack[l.u_off + ((size_t)kk * NT + tau) * 64 + ln] =
+                    (unit < H && cc >= 0) ? kernel[(size_t)(in_dim + unit) * ld + cc] : 0.0f;
+            }
+    for (int tau = 0; tau < NT; ++tau)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r) {
+                const int cc = col(tau, rowmap_h(r, half));
+                pack[l.bias_off + (tau * 2 + half) * 16 + r] = cc >= 0 ? bias[cc] : 0.0f;
+            }
+    for (int u = 0; u < H; ++u)
+        for (int a = 0; a < n_actions; ++a) pack[l.wout_off + (size_t)u * n_actions + a] = w_out[(size_t)u * n_actions + a];
+    for (int a = 0; a < n_actions; ++a) pack[l.bout_off + a] = b_out[a];
+    int rc = ensure(c, c->lstm_w, off * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->lstm_w.p, pack.data(), off * sizeof(float), hipMemcpyHostToDevice));
+    l.set = true;
+    c->lstm = l;
+    return DRL_OK;
+}
+
+}  // extern "C"
+
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct OptDev {
+    const float* in_scale = nullptr;
+    const float* in_offset = nullptr;
+    const float* center = nullptr;
+    const float* scale = nullptr;
+};
+
+// Uploads the small host-side option arrays (per series / per flattened column).
+int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d) {
+    size_t n = 0;
+    if (o->in_scale) n += 2 * up16(n_seg);
+    if (o->vae_center) n += 2 * up16(D);
+    if (!n) return DRL_OK;
+    int rc = ensure(c, c->opt, n * sizeof(float));
+    if (rc) return rc;
+    float* base = (float*)c->opt.p;
+    size_t off = 0;
+    // synchronous small copies: the sources are caller memory that may go away after the call
+    if (o->in_scale) {
+        if (!o->in_offset) return fail(c, DRL_ERR_ARG, "opts.in_scale given without in_offset");
+        HIP_TRY(c, hipMemcpyAsync(base + off, o->in_scale, n_seg * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d.in_scale = base + off; off += up16(n_seg);
+        HIP_TRY(c, hipMemcpyAsync(base + off, o->in_offset, n_seg * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d.in_offset = base + off; off += up16(n_seg);
+    }
+    if (o->vae_center) {
+        if (!o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
+        HIP_TRY(c, hipMemcpyAsync(base + off, o->vae_center, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d.center = base + off; off += up16(D);
+        HIP_TRY(c, hipMemcpyAsync(base + off, o->vae_scale, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d.scale = base + off; off += up16(D);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DRL_OK;
+}
+
+int check_opts(drl_ctx* c, const drl_score_opts* o, int F) {
+    if (!o) return fail(c, DRL_ERR_ARG, "opts is NULL");
+    if (o->struct_size != (int32_t)sizeof(drl_score_opts))
+        return fail(c, DRL_ERR_ARG, "opts.struct_size %d != %zu", o->struct_size, sizeof(drl_score_opts));
+    if (o->vae_lag != 0 && o->vae_lag != 1) return fail(c, DRL_ERR_ARG, "opts.vae_lag must be 0 or 1");
+    if (o->flag_mode < 0 || o->flag_mode > 3) return fail(c, DRL_ERR_ARG, "opts.flag_mode %d", o->flag_mode);
+    if (o->action_rule < 0 || o->action_rule > 1) return fail(c, DRL_ERR_ARG, "opts.action_rule %d", o->action_rule);
+    if (o->flag_mode == DRL_FLAG_EXPLICIT && !o->flags) return fail(c, DRL_ERR_ARG, "explicit flag mode needs opts.flags");
+    if (o->action_rule == DRL_ACTION_WADI && o->flag_mode != DRL_FLAG_BOTH)
+        return fail(c, DRL_ERR_ARG, "the WaDi action rule needs DRL_FLAG_BOTH");
+    (void)F;
+    return DRL_OK;
+}
+
+// Device-pointer core shared by both entry points.
+int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, int n_seg, int F, int W,
+               const drl_score_opts* o, const float* d_flags, const float* d_eps,
+               float* d_err, float* d_q, int32_t* d_action, float* d_margin, long long* K_out) {
+    const bool want_vae = d_err != nullptr;
+    const bool want_q = d_q != nullptr || d_action != nullptr || d_margin != nullptr;
+    if (want_vae) {
+        if (!c->vae.set) return fail(c, DRL_ERR_STATE, "recon_err requested but drl_set_vae was not called");
+        if (c->vae.D != W * F) return fail(c, DRL_ERR_ARG, "VAE input width %d != W*F = %d", c->vae.D, W * F);
+        if (d_eps && (!c->vae.has_lv || c->vae.mu_idx < 1 || c->vae.latent > 32))
+            return fail(c, DRL_ERR_UNSUPPORTED, "eps path needs a logvar layer, an encoder hidden layer and latent <= 32");
+    }
+    if (want_q) {
+        if (!c->lstm.set) return fail(c, DRL_ERR_STATE, "Q requested but drl_set_lstm was not called");
+        if (c->lstm.I != F + 1) return fail(c, DRL_ERR_ARG, "LSTM in_dim %d != F+1 = %d", c->lstm.I, F + 1);
+        if (!d_q) return fail(c, DRL_ERR_ARG, "action/margin need the q output buffer");
+    }
+    SegHost sh;
+    int rc = build_segments(c, seg_offsets, n_seg, W, false, sh);
+    if (rc) return rc;
+    if (K_out) *K_out = sh.K_total;
+    if (sh.K_total == 0) return DRL_OK;
+    OptDev od;
+    rc = upload_opts(c, o, n_seg, W * F, od);
+    if (rc) return rc;
+
+    SegTab seg;
+    seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t32;
+    seg.in_scale = od.in_scale; seg.in_offset = od.in_offset; seg.n_seg = n_seg; seg.W = W;
+
+    if (want_vae) {
+        VaeArgs a;
+        memset(&a, 0, sizeof a);
+        fill_vae_args(c, a);
+        a.x = d_series; a.win_stride = F; a.lag_elems = (1 - o->vae_lag) * F; a.D = W * F;
+        a.center = od.center; a.scale = od.scale; a.clip = o->vae_clip;
+        a.eps = d_eps; a.seg = seg; a.n_tiles = sh.tiles32; a.err = d_err; a.recon = nullptr;
+        prof_begin(c, 1);
+        hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (want_q) {
+        LstmArgs a;
+        memset(&a, 0, sizeof a);
+        fill_lstm_args(c, a);
+        a.W = W; a.x = d_series; a.F = F; a.win_stride = F; a.row_stride = F; a.row0 = 1;
+        a.flag_mode = o->flag_mode; a.flags = d_flags; a.seg = seg;
+        a.S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
+        a.q = d_q;
+        const bool fast = c->lstm.I == 2 && c->lstm.H == 128 && F == 1 && W >= 2 && W + 65 <= H128_SV;
+        prof_begin(c, 0);
+        if (fast) {
+            a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+            hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, a);
+            c->last_variant = "h128i2";
+        } else {
+            a.n_tiles = sh.tiles32;
+            const dim3 grid((sh.tiles32 + 3) / 4, a.S);
+            if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
+            else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
+            c->last_variant = "generic";
+        }
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+        if (d_action || d_margin) {
+            const int bs = 256;
+            hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((sh.K_total + bs - 1) / bs)), dim3(bs), 0, c->stream,
+                               d_q, sh.K_total, a.S, c->lstm.A, o->action_rule, d_action, d_margin);
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
+    return DRL_OK;
+}
+
+long long count_windows(const int64_t* seg_offsets, int n_seg, int W) {
+    long long k = 0;
+    for (int i = 0; i < n_seg; ++i) k += std::max<long long>(0, seg_offsets[i + 1] - seg_offsets[i] - W);
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int drl_score_batch_dev(drl_ctx* c, const float* series, const int64_t* seg_offsets, int n_seg,
+                        int F, int W, const drl_score_opts* o,
+                        float* recon_err, float* q, int32_t* action, float* margin) {
+    if (!c) return DRL_ERR_ARG;
+    if (!series || !seg_offsets || n_seg < 1 || F < 1 || W < 1)
+        return fail(c, DRL_ERR_ARG, "drl_score_batch_dev: bad series/seg_offsets/n_seg/F/W");
+    int rc = check_opts(c, o, F);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return score_impl(c, series, seg_offsets, n_seg, F, W, o, o->flags, o->eps, recon_err, q, action, margin, nullptr);
+}
+
+int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets, int n_seg,
+                    int F, int W, const drl_score_opts* o,
+                    float* recon_err, float* q, int32_t* action, float* margin) {
+    if (!c) return DRL_ERR_ARG;
+    if (!series || !seg_offsets || n_seg < 1 || F < 1 || W < 1)
+        return fail(c, DRL_ERR_ARG, "drl_score_batch: bad series/seg_offsets/n_seg/F/W");
+    int rc = check_opts(c, o, F);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long total = seg_offsets[n_seg] - seg_offsets[0];
+    if (seg_offsets[0] != 0) return fail(c, DRL_ERR_ARG, "seg_offsets[0] must be 0");
+    const long long K = count_windows(seg_offsets, n_seg, W);
+    if (K == 0) return DRL_OK;
+    const int S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
+    const int A = c->lstm.set ? c->lstm.A : 2;
+    const bool want_q = q || action || margin;
+    if ((action || margin) && !q) {
+        // the host entry point can stage q itself
+    }
+    if ((rc = ensure(c, c->st_in, (size_t)total * F * sizeof(float)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const float* d_flags = nullptr;
+    if (o->flag_mode == DRL_FLAG_EXPLICIT) {
+        if ((rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->st_flags.p, o->flags, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_flags = (const float*)c->st_flags.p;
+    }
+    const float* d_eps = nullptr;
+    if (o->eps && recon_err) {
+        if (!c->vae.set) return fail(c, DRL_ERR_STATE, "eps given but drl_set_vae was not called");
+        const size_t n = (size_t)K * c->vae.latent * sizeof(float);
+        if ((rc = ensure(c, c->st_eps, n))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->st_eps.p, o->eps, n, hipMemcpyHostToDevice, c->stream));
+        d_eps = (const float*)c->st_eps.p;
+    }
+    if (recon_err && (rc = ensure(c, c->st_err, (size_t)K * sizeof(float)))) return rc;
+    if (want_q && (rc = ensure(c, c->st_q, (size_t)K * S * A * sizeof(float)))) return rc;
+    if (action && (rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t)))) return rc;
+    if (margin && (rc = ensure(c, c->st_margin, (size_t)K * sizeof(float)))) return rc;
+    rc = score_impl(c, (const float*)c->st_in.p, seg_offsets, n_seg, F, W, o, d_flags, d_eps,
+                    recon_err ? (float*)c->st_err.p : nullptr, want_q ? (float*)c->st_q.p : nullptr,
+                    action ? (int32_t*)c->st_act.p : nullptr, margin ? (float*)c->st_margin.p : nullptr, nullptr);
+    if (rc) return rc;
+    if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (q) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)K * S * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (action) HIP_TRY(c, hipMemcpyAsync(action, c->st_act.p, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (margin) HIP_TRY(c, hipMemcpyAsync(margin, c->st_margin.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DRL_OK;
+}
+
+int drl_score_series(drl_ctx* c, const float* series, int64_t N, int F, int W, const drl_score_opts* o,
+                     float* recon_err, float* q, int32_t* action, float* margin) {
+    const int64_t off[2] = {0, N};
+    return drl_score_batch(c, series, off, 1, F, W, o, recon_err, q, action, margin);
+}
+
+int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, float* recon, float* recon_err) {
+    if (!c) return DRL_ERR_ARG;
+    if (!c->vae.set) return fail(c, DRL_ERR_STATE, "drl_vae_predict: drl_set_vae was not called");
+    if (!x || B < 0 || (!recon && !recon_err)) return fail(c, DRL_ERR_ARG, "drl_vae_predict: bad arguments");
+    if (B == 0) return DRL_OK;
+    if (eps && (!c->vae.has_lv || c->vae.mu_idx < 1 || c->vae.latent > 32))
+        return fail(c, DRL_ERR_UNSUPPORTED, "eps path needs a logvar layer, an encoder hidden layer and latent <= 32");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int D = c->vae.D;
+    int rc;
+    const size_t nb = (size_t)B * D * sizeof(float);
+    if ((rc = ensure(c, c->st_in, nb))) return rc;
+    if ((rc = ensure(c, c->st_q, nb))) return rc;           // reconstruction staging
+    if ((rc = ensure(c, c->st_err, (size_t)B * sizeof(float)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, x, nb, hipMemcpyHostToDevice, c->stream));
+    const float* d_eps = nullptr;
+    if (eps) {
+        const size_t n = (size_t)B * c->vae.latent * sizeof(float);
+        if ((rc = ensure(c, c->st_eps, n))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->st_eps.p, eps, n, hipMemcpyHostToDevice, c->stream));
+        d_eps = (const float*)c->st_eps.p;
+    }
+    const int64_t off[2] = {0, B};
+    SegHost sh;
+    if ((rc = build_segments(c, off, 1, 0, true, sh))) return rc;
+    VaeArgs a;
+    memset(&a, 0, sizeof a);
+    fill_vae_args(c, a);
+    a.x = (const float*)c->st_in.p; a.win_stride = D; a.lag_elems = 0; a.D = D;
+    a.eps = d_eps;
+    a.seg.samp_off = sh.d_samp; a.seg.win_off = sh.d_win; a.seg.tile_off = sh.d_t32; a.seg.n_seg = 1; a.seg.W = 0;
+    a.n_tiles = sh.tiles32;
+    a.err = (float*)c->st_err.p;
+    a.recon = recon ? (float*)c->st_q.p : nullptr;
+    prof_begin(c, 1);
+    hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    if (recon) HIP_TRY(c, hipMemcpyAsync(recon, c->st_q.p, nb, hipMemcpyDeviceToHost, c->stream));
+    if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DRL_OK;
+}
+
+int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
+    if (!c) return DRL_ERR_ARG;
+    if (!c->lstm.set) return fail(c, DRL_ERR_STATE, "drl_q_predict: drl_set_lstm was not called");
+    if (!states || !q || B < 0 || W < 1) return fail(c, DRL_ERR_ARG, "drl_q_predict: bad arguments");
+    if (B == 0) return DRL_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int I = c->lstm.I, A = c->lstm.A;
+    int rc;
+    const size_t nb = (size_t)B * W * I * sizeof(float);
+    if ((rc = ensure(c, c->st_in, nb))) return rc;
+    if ((rc = ensure(c, c->st_q, (size_t)B * A * sizeof(float)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, states, nb, hipMemcpyHostToDevice, c->stream));
+    const int64_t off[2] = {0, B};
+    SegHost sh;
+    if ((rc = build_segments(c, off, 1, 0, true, sh))) return rc;
+    LstmArgs a;
+    memset(&a, 0, sizeof a);
+    fill_lstm_args(c, a);
+    a.W = W; a.x = (const float*)c->st_in.p; a.F = I; a.win_stride = (long long)W * I; a.row_stride = I; a.row0 = 0;
+    a.flag_mode = -1; a.flags = nullptr;
+    a.seg.samp_off = sh.d_samp; a.seg.win_off = sh.d_win; a.seg.tile_off = sh.d_t32; a.seg.n_seg = 1; a.seg.W = W;
+    a.n_tiles = sh.tiles32; a.S = 1; a.q = (float*)c->st_q.p;
+    // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
+    const dim3 grid((sh.tiles32 + 3) / 4, 1);
+    prof_begin(c, 0);
+    if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
+    prof_end(c);
+    c->last_variant = "generic";
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DRL_OK;
+}
+
+int drl_profile_enable(drl_ctx* c, int on) {
+    if (!c) return DRL_ERR_ARG;
+    c->prof.on = on != 0;
+    return DRL_OK;
+}
+int drl_profile_reset(drl_ctx* c) {
+    if (!c) return DRL_ERR_ARG;
+    int rc = prof_collect(c);
+    c->prof.ms[0] = c->prof.ms[1] = 0;
+    c->prof.n[0] = c->prof.n[1] = 0;
+    return rc;
+}
+int drl_profile_read(drl_ctx* c, int which, double* total_ms, int64_t* launches) {
+    if (!c || which < 0 || which > 1) return DRL_ERR_ARG;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->prof.ms[which];
+    if (launches) *launches = c->prof.n[which];
+    return DRL_OK;
+}
+const char* drl_last_lstm_variant(drl_ctx* c) { return c ? c->last_variant : "none"; }
+
+}  // extern "C"

@@ -1,0 +1,532 @@
+// CDNA4 (gfx950) kernels of the window-scoring path.  Wave = 64 lanes.
+//
+// Everything GEMM-shaped runs on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain) in
+// the "transposed" orientation D[row = output feature][col = window]:
+//   A operand (1 VGPR): lane l holds A[row = l&31][k = l>>5]   -> a weight, pre-packed on the host
+//   B operand (1 VGPR): lane l holds B[k = l>>5][col = l&31]   -> an activation of window l&31
+//   C/D (16 VGPRs):     lane l, reg r holds D[row = rowmap(r, l>>5)][col = l&31],
+//                       rowmap(r, h) = (r&3) + 8*(r>>2) + 4*h
+// With this orientation an accumulator register *is* a valid B operand of the next product
+// (k-step r of an input tile pairs rows rowmap(r,0) and rowmap(r,1)), so activations chain from
+// layer to layer, and h_t feeds step t+1, without leaving the register file; the weights are
+// packed on the host in exactly that k order (pack_* in drlvae.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DRL_MAX_VAE_LAYERS 8
+#define DRL_VAE_MAX_TILES 4   // hidden widths <= 128
+
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// sigmoid / tanh through v_exp_f32 + v_rcp_f32 (both 1 ulp): absolute error ~1e-7.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)) - 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Series segments.  Windows never cross a series; a "tile" is a run of consecutive windows of one
+// series (32 for the per-wave kernels, 64 for the h128i2 workgroup kernel).
+struct SegTab {
+    const long long* samp_off;  // [n_seg+1] first sample of each series in the concatenated input
+    const long long* win_off;   // [n_seg+1] first output window of each series
+    const int* tile_off;        // [n_seg+1] first tile of each series
+    const float* in_scale;      // [n_seg] or null
+    const float* in_offset;     // [n_seg] or null
+    int n_seg;
+    int W;
+};
+
+__device__ __forceinline__ int find_seg(const int* __restrict__ tile_off, int n_seg, int tile) {
+    int lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (tile_off[mid] <= tile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// reference env.py:78-79 (sklearn MinMaxScaler): x*scale_ + min_ with two float32 roundings
+__device__ __forceinline__ float minmax_apply(float x, float sc, float of) {
+    float m = x * sc;
+    asm volatile("" : "+v"(m));        // keep the product rounded: no fma contraction
+    return m + of;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: VAE mean path + reconstruction error.  One wave = 32 windows, no LDS, no barriers.
+struct VaeArgs {
+    // path = encoder hidden..., mu, decoder...  (the logvar head rides beside mu when eps != null)
+    int n;                                   // layers on the path (>= 2)
+    int din[DRL_MAX_VAE_LAYERS];
+    int dout[DRL_MAX_VAE_LAYERS];
+    int act[DRL_MAX_VAE_LAYERS];
+    const float* w[DRL_MAX_VAE_LAYERS];      // packed [out_tile][in_tile][16][64]
+    const float* b[DRL_MAX_VAE_LAYERS];      // packed [out_tile][2][16]
+    int mu_idx;                              // position of mu on the path
+    const float* w_lv;                       // packed like w[mu_idx]
+    const float* b_lv;
+    float lv_clip;                           // <= 0: none
+    // input
+    const float* x;                          // flat series [samples*F] or explicit batch [B*D]
+    long long win_stride;                    // elements between consecutive windows (F, or D)
+    int lag_elems;                           // element offset of window 0 inside its series: (1-lag)*F
+    int D;                                   // window length in elements (W*F)
+    const float* center;                     // [D] or null (RobustScaler)
+    const float* scale;                      // [D]
+    float clip;                              // <= 0: none
+    const float* eps;                        // [K_total, latent] or null
+    SegTab seg;
+    int n_tiles;
+    // outputs
+    float* err;                              // [K_total] or null
+    float* recon;                            // [K_total, D] or null (drl_vae_predict)
+};
+
+__device__ __forceinline__ float apply_act(float y, int act) {
+    if (act == 1) return fmaxf(y, 0.0f);
+    if (act == 2) return fast_sigmoid(y);
+    return y;
+}
+
+__device__ __forceinline__ f32x16 load_bias16(const float* __restrict__ bp, int tile, int half) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(bp + (tile * 2 + half) * 16);
+    f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    v[8] = c[0]; v[9] = c[1]; v[10] = c[2]; v[11] = c[3];
+    v[12] = d[0]; v[13] = d[1]; v[14] = d[2]; v[15] = d[3];
+    return v;
+}
+
+__device__ __forceinline__ float vae_input(const VaeArgs& a, const float* __restrict__ xin, int d,
+                                           bool has_norm, float sc, float of) {
+    if (d >= a.D) return 0.0f;
+    float v = xin[d];
+    if (has_norm) v = minmax_apply(v, sc, of);
+    if (a.center) {
+        v = (v - a.center[d]) / a.scale[d];
+        if (a.clip > 0.0f) v = fminf(fmaxf(v, -a.clip), a.clip);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.n_tiles) return;                       // wave-uniform
+    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
+    const long long samp0 = a.seg.samp_off[s];
+    const long long nsamp = a.seg.samp_off[s + 1] - samp0;
+    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
+    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 32;
+    const int count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
+    const int jj = j < count ? j : count - 1;
+    (void)nsamp;
+    const bool has_norm = a.seg.in_scale != nullptr;
+    const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+    const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+    const float* __restrict__ xin = a.x + samp0 * a.win_stride + a.lag_elems + (k0 + jj) * a.win_stride;
+    const long long wout = a.seg.win_off[s] + k0 + jj;
+
+    f32x16 cur[DRL_VAE_MAX_TILES], nxt[DRL_VAE_MAX_TILES];
+
+    // ---- layer 0: input from memory
+    {
+        const int nin = (a.din[0] + 31) >> 5, nout = (a.dout[0] + 31) >> 5;
+        const float* __restrict__ w = a.w[0];
+#pragma unroll
+        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+            cur[ot] = ot < nout ? load_bias16(a.b[0], ot, half) : f32x16{};
+        for (int it = 0; it < nin; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bv = vae_input(a, xin, it * 32 + rowmap(r, half), has_norm, sc, of);
+#pragma unroll
+                for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+                    if (ot < nout)
+                        cur[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], bv, cur[ot]);
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(cur[ot][r], a.act[0]);
+    }
+
+    // ---- middle layers: registers -> registers
+    for (int p = 1; p < a.n - 1; ++p) {
+        const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
+        const float* __restrict__ w = a.w[p];
+        const bool with_lv = (p == a.mu_idx) && a.eps != nullptr;
+        f32x16 lv = {};
+#pragma unroll
+        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+            nxt[ot] = ot < nout ? load_bias16(a.b[p], ot, half) : f32x16{};
+        if (with_lv) lv = load_bias16(a.b_lv, 0, half);
+#pragma unroll
+        for (int it = 0; it < DRL_VAE_MAX_TILES; ++it) {
+            if (it < nin) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                    for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+                        if (ot < nout)
+                            nxt[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], nxt[ot]);
+                    if (with_lv)   // latent <= 32: one output tile
+                        lv = mfma32(a.w_lv[(((size_t)it) * 16 + r) * 64 + lane], cur[it][r], lv);
+                }
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(nxt[ot][r], a.act[p]);
+        if (with_lv) {
+            // z = mu + exp(0.5*clip(logvar))*eps   (reference myasp-A1.py:84, 94)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = rowmap(r, half);
+                if (d < a.dout[p]) {
+                    float l = lv[r];
+                    if (a.lv_clip > 0.0f) l = fminf(fmaxf(l, -a.lv_clip), a.lv_clip);
+                    cur[0][r] += __expf(0.5f * l) * a.eps[wout * a.dout[p] + d];
+                }
+            }
+        }
+    }
+
+    // ---- last layer: registers -> sigmoid -> squared error against the input
+    {
+        const int p = a.n - 1;
+        const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
+        const float* __restrict__ w = a.w[p];
+        float sq = 0.0f;
+        for (int ot = 0; ot < nout; ++ot) {
+            f32x16 acc = load_bias16(a.b[p], ot, half);
+#pragma unroll
+            for (int it = 0; it < DRL_VAE_MAX_TILES; ++it) {
+                if (it < nin) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = ot * 32 + rowmap(r, half);
+                const float y = apply_act(acc[r], a.act[p]);
+                const float xv = vae_input(a, xin, d, has_norm, sc, of);
+                if (d < a.D) {
+                    const float df = y - xv;
+                    sq = fmaf(df, df, sq);
+                    if (a.recon && j < count) a.recon[wout * a.D + d] = y;
+                }
+            }
+        }
+        sq += __shfl_xor(sq, 32);                      // the two halves hold different rows
+        if (a.err && half == 0 && j < count) a.err[wout] = sq / (float)a.D;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: LSTM-DQN.
+struct LstmArgs {
+    int I, H, A, W;
+    float forget_bias;
+    const float* wx;        // packed [ceil(I/2)][NT][64]
+    const float* u;         // packed [H/2][NT][64]
+    const float* bias;      // packed [NT][2][16]
+    const float* w_out;     // [H][A]
+    const float* b_out;     // [A]
+    // input
+    const float* x;         // series [samples, F] or explicit states [B, W, I]
+    int F;                  // features taken from x per row (I-1 when the flag is synthesised, I when explicit states)
+    long long win_stride;   // elements between windows (F, or W*I)
+    long long row_stride;   // elements between rows of one window (F, or I)
+    int row0;               // first row of window 0 relative to the series start (1, or 0)
+    int flag_mode;          // drl_flag_mode; -1 = no synthesised flag (explicit states)
+    const float* flags;     // per-sample flags (explicit mode)
+    SegTab seg;
+    int n_tiles;
+    int S;                  // candidate states per window (gridDim.y)
+    float* q;               // [K_total, S, A]
+};
+
+__device__ __forceinline__ float synth_flag(int mode, long long k, int t, int W, int cand,
+                                            const float* __restrict__ flags, long long sample) {
+    if (mode == 1) return (k < W && t == W - 1 - (int)k) ? 1.0f : 0.0f;
+    if (mode == 2) return flags[sample];
+    if (mode == 3) return (float)cand;
+    return 0.0f;
+}
+
+// One LSTM cell update for the four gate registers of one (unit, window).
+__device__ __forceinline__ float lstm_cell(float zi, float zj, float zf, float zo, float fb, float& c) {
+    c = fast_sigmoid(zf + fb) * c + fast_sigmoid(zi) * fast_tanh(zj);
+    return fast_sigmoid(zo) * fast_tanh(c);
+}
+
+// Generic shapes: one wave = 32 windows of one candidate state, weights streamed from L2 in
+// packed A-fragment order (256 B per MFMA, coalesced).  c stays in registers; h_t is parked in a
+// wave-private LDS slab in B-fragment order (each lane re-reads exactly what it wrote, so no
+// barrier is needed) so that the k loop can stay a rolled loop.
+// NT = gate tiles (tile tau, row i: unit 8*tau + (i>>2), gate i&3); H <= 8*NT, zero padded.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void lstm_generic_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_h[4][NT * 4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.n_tiles) return;
+    const int cand = blockIdx.y;
+    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
+    const long long samp0 = a.seg.samp_off[s];
+    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
+    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 32;
+    const int count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
+    const int jj = j < count ? j : count - 1;
+    const long long k = k0 + jj;
+    const bool has_norm = a.seg.in_scale != nullptr;
+    const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+    const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+    const float* __restrict__ xw = a.x + samp0 * a.row_stride + (long long)a.row0 * a.row_stride + k * a.win_stride;
+    const long long flag_base = samp0 + a.row0 + k;      // sample index of row 0 (explicit flags)
+    const int nks = (a.I + 1) >> 1;
+    float* __restrict__ hw = &s_h[wave][0][lane];
+
+    f32x16 acc[NT];
+    float c[NT][4];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) c[tl][qd] = 0.0f;
+
+    for (int t = 0; t < a.W; ++t) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc[tl] = load_bias16(a.bias, tl, half);
+        // input part: [x_t, flag] . Wx
+        const float* __restrict__ xr = xw + (long long)t * a.row_stride;
+#pragma unroll 2
+        for (int ks = 0; ks < nks; ++ks) {
+            const int feat = 2 * ks + half;
+            float bv = 0.0f;
+            if (feat < a.F) {
+                bv = xr[feat];
+                if (has_norm) bv = minmax_apply(bv, sc, of);
+            } else if (feat == a.F && a.flag_mode >= 0) {
+                bv = synth_flag(a.flag_mode, k, t, a.W, cand, a.flags, flag_base + t);
+            }
+            const float* __restrict__ wp = a.wx + ((size_t)ks * NT) * 64 + lane;
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(wp[tl * 64], bv, acc[tl]);
+        }
+        // recurrent part: h_{t-1} . U
+        if (t > 0) {
+#pragma unroll 2
+            for (int kk = 0; kk < NT * 4; ++kk) {
+                const float hv = hw[kk * 64];
+                const float* __restrict__ up = a.u + ((size_t)kk * NT) * 64 + lane;
+#pragma unroll
+                for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(up[tl * 64], hv, acc[tl]);
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                hw[(tl * 4 + qd) * 64] = lstm_cell(acc[tl][4 * qd], acc[tl][4 * qd + 1], acc[tl][4 * qd + 2],
+                                                   acc[tl][4 * qd + 3], a.forget_bias, c[tl][qd]);
+            __builtin_amdgcn_sched_barrier(0);          // keep live ranges short: one tile at a time
+        }
+    }
+
+    // Q head: lane holds units 8*tl + 2*qd + half of window j
+    for (int act = 0; act < a.A; ++act) {
+        float part = 0.0f;
+        for (int kk = 0; kk < NT * 4; ++kk) {
+            const int unit = 8 * (kk >> 2) + 2 * (kk & 3) + half;
+            if (unit < a.H) part = fmaf(hw[kk * 64], a.w_out[unit * a.A + act], part);
+        }
+        part += __shfl_xor(part, 32);
+        if (half == 0 && j < count)
+            a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = part + a.b_out[act];
+    }
+}
+
+// Univariate fast path (I = 2, H = 128): one workgroup of 4 waves = 64 consecutive windows in two
+// groups of 32.  The recurrent weights U (256 KiB fp32) do not fit the 160 KiB LDS, so they live
+// in the CU's register file for the whole kernel: wave w owns gate tiles 4w..4w+3 (32 hidden units
+// x 4 gates) = 256 VGPRs/AGPRs of A fragments.  Only h_t (32 windows x 128 units = 16 KiB per
+// group) crosses waves, through LDS, already in B-fragment order.  The two groups run half a step
+// apart: while the MFMAs of one group run, the gate non-linearities of the other group issue on
+// the VALU of the same wave.
+#define H128_SV 256
+__device__ __forceinline__ void h128_gemm(f32x16 (&acc)[4], const float (&U)[4][64], const float (&wx)[4],
+                                          const float* __restrict__ hb, const float* __restrict__ bias_l,
+                                          float bx, int lane, int half, int w) {
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        acc[tl] = load_bias16(bias_l, 4 * w + tl, half);
+        acc[tl] = mfma32(wx[tl], bx, acc[tl]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+        const float b = hb[kk * 64 + lane];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) acc[tl] = mfma32(U[tl][kk], b, acc[tl]);
+    }
+}
+
+__device__ __forceinline__ void h128_xonly(f32x16 (&acc)[4], const float (&wx)[4],
+                                           const float* __restrict__ bias_l, float bx, int half, int w) {
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        acc[tl] = load_bias16(bias_l, 4 * w + tl, half);
+        acc[tl] = mfma32(wx[tl], bx, acc[tl]);
+    }
+}
+
+__device__ __forceinline__ void h128_pointwise(const f32x16 (&acc)[4], float (&c)[4][4], float* __restrict__ hb,
+                                               float fb, int lane, int w) {
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float hv = lstm_cell(acc[tl][4 * qd], acc[tl][4 * qd + 1], acc[tl][4 * qd + 2],
+                                       acc[tl][4 * qd + 3], fb, c[tl][qd]);
+            hb[((4 * w + tl) * 4 + qd) * 64 + lane] = hv;
+        }
+}
+
+__global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
+    // separate objects so that alias analysis can tell group A's h from group B's
+    __shared__ __attribute__((aligned(16))) float s_hA[64 * 64];   // [k-step][lane]
+    __shared__ __attribute__((aligned(16))) float s_hB[64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_bias[16 * 2 * 16];
+    __shared__ float s_sv[H128_SV];          // normalised samples k0 .. k0+64+W
+    __shared__ float s_sf[H128_SV];          // explicit flags of those samples
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    const int tile = blockIdx.x;
+    const int cand = blockIdx.y;
+    const int W = a.W;
+    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
+    const long long samp0 = a.seg.samp_off[s];
+    const long long nsamp = a.seg.samp_off[s + 1] - samp0;
+    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
+    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 64;
+    const int count = (int)(Ks - k0 < 64 ? Ks - k0 : 64);
+
+    // stage the series tile (and explicit flags) into LDS, coalesced, clamped to the series
+    {
+        const bool has_norm = a.seg.in_scale != nullptr;
+        const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+        const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+        for (int i = threadIdx.x; i < 64 + W + 1 && i < H128_SV; i += 256) {
+            long long n = k0 + i;
+            if (n > nsamp - 1) n = nsamp - 1;
+            float v = a.x[samp0 + n];
+            if (has_norm) v = minmax_apply(v, sc, of);
+            s_sv[i] = v;
+            s_sf[i] = (a.flag_mode == 2) ? a.flags[samp0 + n] : 0.0f;
+        }
+        for (int i = threadIdx.x; i < 16 * 2 * 16; i += 256) s_bias[i] = a.bias[i];
+    }
+
+    // weights to registers
+    float U[4][64], wx[4];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) {
+        wx[tl] = a.wx[(4 * w + tl) * 64 + lane];
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) U[tl][kk] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
+    }
+    __syncthreads();
+
+    const float* bias_l = s_bias;
+    float* hA = s_hA;
+    float* hB = s_hB;
+    const float fb = a.forget_bias;
+    f32x16 accA[4], accB[4];
+    float cA[4][4], cB[4][4];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) { cA[tl][qd] = 0.0f; cB[tl][qd] = 0.0f; }
+
+    // B operand of the input k-step: lanes 0-31 carry the value, lanes 32-63 the flag
+    auto xin = [&](int g, int t) -> float {
+        const int li = g * 32 + j + 1 + t;                 // local sample index of row t
+        if (half == 0) return s_sv[li];
+        if (a.flag_mode == 2) return s_sf[li];
+        return synth_flag(a.flag_mode, k0 + g * 32 + j, t, W, cand, nullptr, 0);
+    };
+
+    // step 0: h = 0, only the input part
+    h128_xonly(accA, wx, bias_l, xin(0, 0), half, w);
+    h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
+    h128_pointwise(accA, cA, hA, fb, lane, w);
+    __syncthreads();
+    for (int t = 1; t < W; ++t) {
+        // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
+        const float bxa = xin(0, t);
+        h128_pointwise(accB, cB, hB, fb, lane, w);
+        h128_gemm(accA, U, wx, hA, bias_l, bxa, lane, half, w);
+        __syncthreads();
+        // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
+        const float bxb = xin(1, t);
+        h128_pointwise(accA, cA, hA, fb, lane, w);
+        h128_gemm(accB, U, wx, hB, bias_l, bxb, lane, half, w);
+        __syncthreads();
+    }
+    h128_pointwise(accB, cB, hB, fb, lane, w);
+    __syncthreads();
+
+    // Q head: waves 0/1 -> groups A/B; lane sums the units of its half, then the halves combine
+    if (w < 2) {
+        const float* hb = w == 0 ? hA : hB;
+        const int jw = w * 32 + j;
+        for (int act = 0; act < a.A; ++act) {
+            float part = 0.0f;
+#pragma unroll 8
+            for (int kk = 0; kk < 64; ++kk)
+                part = fmaf(hb[kk * 64 + lane], a.w_out[((kk >> 2) * 8 + 2 * (kk & 3) + half) * a.A + act], part);
+            part += __shfl_xor(part, 32);
+            if (half == 0 && jw < count)
+                a.q[((a.seg.win_off[s] + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// action + AL margin from Q (reference myasp-A1.py:227, 255; myasp-wadi.py:328)
+__global__ void finalize_kernel(const float* __restrict__ q, long long K, int S, int A, int rule,
+                                int* __restrict__ action, float* __restrict__ margin) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float q0, q1;
+    if (rule == 1) { q0 = q[(k * S + 0) * A + 0]; q1 = q[(k * S + 1) * A + 1]; }
+    else           { q0 = q[k * S * A + 0];       q1 = q[k * S * A + 1]; }
+    if (action) {
+        int best = q1 > q0 ? 1 : 0;
+        if (rule == 0) {                                  // np.argmax over all A actions
+            float bv = best ? q1 : q0;
+            for (int i = 2; i < A; ++i) { const float v = q[k * S * A + i]; if (v > bv) { bv = v; best = i; } }
+        }
+        action[k] = best;
+    }
+    if (margin) margin[k] = fabsf(q0 - q1);
+}

@@ -1,0 +1,81 @@
+"""ctypes binding of libdrlvae.so (include/drlvae.h).  No fallback: when the library or a GPU is
+missing every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrlvae.so")
+
+FLAG_ZEROS, FLAG_QUIRK, FLAG_EXPLICIT, FLAG_BOTH = 0, 1, 2, 3
+ACTION_ARGMAX, ACTION_WADI = 0, 1
+
+# every symbol include/drlvae.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
+    "drl_set_vae", "drl_set_lstm", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
+    "drl_vae_predict", "drl_q_predict", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
+    "drl_last_lstm_variant",
+]
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class ScoreOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("vae_lag", C.c_int32),
+        ("flag_mode", C.c_int32),
+        ("action_rule", C.c_int32),
+        ("flags", C.c_void_p),
+        ("eps", C.c_void_p),
+        ("in_scale", C.c_void_p),
+        ("in_offset", C.c_void_p),
+        ("vae_center", C.c_void_p),
+        ("vae_scale", C.c_void_p),
+        ("vae_clip", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Loads libdrlvae.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the scoring path.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.drl_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.drl_destroy.argtypes = [vp]
+    lib.drl_destroy.restype = None
+    lib.drl_last_error.argtypes = [vp]
+    lib.drl_last_error.restype = C.c_char_p
+    lib.drl_version.restype = C.c_char_p
+    lib.drl_set_stream.argtypes = [vp, vp]
+    lib.drl_synchronize.argtypes = [vp]
+    lib.drl_set_vae.argtypes = [vp, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int,
+                                C.POINTER(vp), C.POINTER(vp), C.c_float]
+    lib.drl_set_lstm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]
+    score_args = [vp, vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(ScoreOpts), vp, vp, vp, vp]
+    lib.drl_score_batch.argtypes = score_args
+    lib.drl_score_batch_dev.argtypes = score_args
+    lib.drl_score_series.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.POINTER(ScoreOpts), vp, vp, vp, vp]
+    lib.drl_vae_predict.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
+    lib.drl_q_predict.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
+    lib.drl_profile_enable.argtypes = [vp, C.c_int]
+    lib.drl_profile_reset.argtypes = [vp]
+    lib.drl_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), _i64p]
+    lib.drl_last_lstm_variant.argtypes = [vp]
+    lib.drl_last_lstm_variant.restype = C.c_char_p
+    _lib = lib
+    return lib

@@ -1,0 +1,229 @@
+"""WindowScorer: the host-side handle on the MI355X scoring path (one per GPU / process).
+
+Everything numeric happens in libdrlvae.so (hand-written gfx950 kernels); this module only
+marshals numpy / torch buffers across the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+_MODES = {"zeros": _abi.FLAG_ZEROS, "quirk": _abi.FLAG_QUIRK, "explicit": _abi.FLAG_EXPLICIT,
+          "both": _abi.FLAG_BOTH}
+_RULES = {"argmax": _abi.ACTION_ARGMAX, "wadi": _abi.ACTION_WADI}
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a) -> Optional[int]:
+    return None if a is None else a.ctypes.data
+
+
+class WindowScorer:
+    def __init__(self, device: int = 0):
+        self._lib = _abi.load()
+        h = C.c_void_p()
+        rc = self._lib.drl_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"drl_create({device}) failed ({rc}): "
+                               f"{self._lib.drl_last_error(None).decode()}")
+        self._h = h
+        self.device = int(device)
+        self.latent = 0
+        self.n_actions = 2
+        self.vae_dim = 0
+        self.lstm_in = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.drl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._lib.drl_last_error(self._h).decode()}")
+
+    def synchronize(self):
+        self._check(self._lib.drl_synchronize(self._h), "drl_synchronize")
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.drl_set_stream(self._h, C.c_void_p(hip_stream or 0)), "drl_set_stream")
+
+    # ------------------------------------------------------------------ weights
+    def set_vae(self, vae: Dict):
+        """vae: {"kernels", "biases", "acts", "mu_layer", "logvar_layer", "logvar_clip"} in the
+        layer order encoder hidden..., mu, logvar, decoder... (drlvae.formats.load_keras_vae /
+        drlvae.compat.vae_from_dense_chain produce it)."""
+        ks = [_f32(k) for k in vae["kernels"]]
+        bs = [_f32(b) for b in vae["biases"]]
+        n = len(ks)
+        ind = (C.c_int32 * n)(*[k.shape[0] for k in ks])
+        outd = (C.c_int32 * n)(*[k.shape[1] for k in ks])
+        acts = (C.c_int32 * n)(*[int(a) for a in vae["acts"]])
+        kp = (C.c_void_p * n)(*[k.ctypes.data for k in ks])
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        clip = vae.get("logvar_clip", 10.0)
+        clip = float("inf") if clip is None else float(clip)
+        lv = vae.get("logvar_layer", -1)
+        self._check(self._lib.drl_set_vae(self._h, n, ind, outd, acts, int(vae["mu_layer"]),
+                                          -1 if lv is None else int(lv), kp, bp, clip), "drl_set_vae")
+        self.latent = ks[int(vae["mu_layer"])].shape[1]
+        self.vae_dim = ks[0].shape[0]
+
+    def set_lstm(self, lstm: Dict):
+        """lstm: {"kernel" [I+H,4H] (i|j|f|o), "bias" [4H], "w_out" [H,A], "b_out" [A],
+        optional "forget_bias"} (drlvae.formats.load_q_estimator produces it)."""
+        k, b = _f32(lstm["kernel"]), _f32(lstm["bias"])
+        wo, bo = _f32(lstm["w_out"]), _f32(lstm["b_out"])
+        H = k.shape[1] // 4
+        I = k.shape[0] - H
+        if k.shape[1] != 4 * H or b.shape != (4 * H,) or wo.shape[0] != H or bo.shape != (wo.shape[1],):
+            raise ValueError("inconsistent LSTM weight shapes")
+        self._check(self._lib.drl_set_lstm(self._h, I, H, wo.shape[1], float(lstm.get("forget_bias", 1.0)),
+                                           k.ctypes.data, b.ctypes.data, wo.ctypes.data, bo.ctypes.data),
+                    "drl_set_lstm")
+        self.n_actions = wo.shape[1]
+        self.lstm_in = I
+
+    # ------------------------------------------------------------------ options
+    def _opts(self, keep, vae_lag, flag_mode, action_rule, flags=None, eps=None, in_scale=None,
+              in_offset=None, vae_center=None, vae_scale=None, vae_clip=0.0, dev=False):
+        o = _abi.ScoreOpts()
+        o.struct_size = C.sizeof(_abi.ScoreOpts)
+        o.vae_lag = int(vae_lag)
+        o.flag_mode = _MODES[flag_mode] if isinstance(flag_mode, str) else int(flag_mode)
+        o.action_rule = _RULES[action_rule] if isinstance(action_rule, str) else int(action_rule)
+
+        def host(a):
+            if a is None:
+                return None
+            a = _f32(a)
+            keep.append(a)
+            return a.ctypes.data
+
+        if dev:
+            o.flags = None if flags is None else int(flags.data_ptr())
+            o.eps = None if eps is None else int(eps.data_ptr())
+            keep.extend([flags, eps])
+        else:
+            o.flags = host(flags)
+            o.eps = host(eps)
+        o.in_scale = host(in_scale)
+        o.in_offset = host(in_offset)
+        o.vae_center = host(vae_center)
+        o.vae_scale = host(vae_scale)
+        o.vae_clip = float(vae_clip or 0.0)
+        return o
+
+    @staticmethod
+    def window_counts(offsets: np.ndarray, W: int) -> np.ndarray:
+        n = np.diff(offsets)
+        return np.maximum(n - W, 0)
+
+    # ------------------------------------------------------------------ fused path, host buffers
+    def score(self, series, W: int, offsets: Optional[Sequence[int]] = None, *, vae_lag: int = 1,
+              flag_mode="quirk", action_rule="argmax", want=("err", "q", "action", "margin"),
+              **opt) -> Dict[str, np.ndarray]:
+        """Scores every window of one series ([N] or [N,F]) or of several concatenated series
+        (``offsets`` = n_seg+1 sample offsets).  Returns numpy arrays keyed by ``want``."""
+        x = _f32(series)
+        if x.ndim == 1:
+            x = x[:, None]
+        N, F = x.shape
+        off = np.ascontiguousarray([0, N] if offsets is None else offsets, dtype=np.int64)
+        if off[0] != 0 or off[-1] != N:
+            raise ValueError("offsets must start at 0 and end at the number of samples")
+        K = int(self.window_counts(off, W).sum())
+        S = 2 if flag_mode in ("both", _abi.FLAG_BOTH) else 1
+        keep = []
+        o = self._opts(keep, vae_lag, flag_mode, action_rule, **opt)
+        out = {}
+        if "err" in want:
+            out["err"] = np.empty(K, np.float32)
+        need_q = any(w in want for w in ("q", "action", "margin"))
+        if need_q:
+            out["q"] = np.empty((K, S, self.n_actions) if S == 2 else (K, self.n_actions), np.float32)
+        if "action" in want:
+            out["action"] = np.empty(K, np.int32)
+        if "margin" in want:
+            out["margin"] = np.empty(K, np.float32)
+        rc = self._lib.drl_score_batch(self._h, x.ctypes.data, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       len(off) - 1, F, int(W), C.byref(o),
+                                       _ptr(out.get("err")), _ptr(out.get("q")),
+                                       _ptr(out.get("action")), _ptr(out.get("margin")))
+        self._check(rc, "drl_score_batch")
+        if need_q and "q" not in want:
+            del out["q"]
+        return out
+
+    # ------------------------------------------------------------------ fused path, device buffers
+    def score_dev(self, series, W: int, offsets, out: Dict, *, vae_lag: int = 1, flag_mode="zeros",
+                  action_rule="argmax", **opt):
+        """Device-resident variant: ``series`` and the tensors in ``out`` ("err", "q", "action",
+        "margin"; any subset) are torch tensors on this scorer's GPU.  Asynchronous on the
+        scorer's stream (see set_stream)."""
+        if series.dtype.__str__() != "torch.float32" or not series.is_contiguous():
+            raise ValueError("series must be a contiguous float32 tensor")
+        F = 1 if series.dim() == 1 else series.shape[1]
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        keep = []
+        o = self._opts(keep, vae_lag, flag_mode, action_rule, dev=True, **opt)
+
+        def dp(name):
+            t = out.get(name)
+            return None if t is None else int(t.data_ptr())
+
+        rc = self._lib.drl_score_batch_dev(self._h, int(series.data_ptr()),
+                                           off.ctypes.data_as(C.POINTER(C.c_int64)), len(off) - 1, F, int(W),
+                                           C.byref(o), dp("err"), dp("q"), dp("action"), dp("margin"))
+        self._check(rc, "drl_score_batch_dev")
+
+    # ------------------------------------------------------------------ call-surface compatibility
+    def vae_predict(self, x, eps=None, return_err: bool = False):
+        x = _f32(x)
+        if x.ndim != 2 or x.shape[1] != self.vae_dim:
+            raise ValueError(f"expected (B, {self.vae_dim}) input, got {x.shape}")
+        rec = np.empty_like(x)
+        err = np.empty(x.shape[0], np.float32)
+        e = None if eps is None else _f32(eps)
+        self._check(self._lib.drl_vae_predict(self._h, x.ctypes.data, x.shape[0], _ptr(e),
+                                              rec.ctypes.data, err.ctypes.data), "drl_vae_predict")
+        return (rec, err) if return_err else rec
+
+    def q_predict(self, states):
+        s = _f32(states)
+        if s.ndim != 3 or s.shape[2] != self.lstm_in:
+            raise ValueError(f"expected (B, W, {self.lstm_in}) states, got {s.shape}")
+        q = np.empty((s.shape[0], self.n_actions), np.float32)
+        self._check(self._lib.drl_q_predict(self._h, s.ctypes.data, s.shape[0], s.shape[1], q.ctypes.data),
+                    "drl_q_predict")
+        return q
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on: bool):
+        self._check(self._lib.drl_profile_enable(self._h, 1 if on else 0), "drl_profile_enable")
+
+    def profile_reset(self):
+        self._check(self._lib.drl_profile_reset(self._h), "drl_profile_reset")
+
+    def profile_read(self, which: int):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self._lib.drl_profile_read(self._h, which, C.byref(ms), C.byref(n)), "drl_profile_read")
+        return ms.value, n.value
+
+    @property
+    def lstm_variant(self) -> str:
+        return self._lib.drl_last_lstm_variant(self._h).decode()

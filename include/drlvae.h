@@ -1,0 +1,171 @@
+/*
+ * libdrlvae — C-ABI of the MI355X window-scoring path (VAE reward + LSTM-DQN Q / action).
+ *
+ * The reference (baharehgl/Dynamic-Reward-RL-VAE) has no FFI layer: the path is reached through
+ * Python call sites (vae.predict, estimator.predict, env.statefnc / env.rewardfnc, penalty_array,
+ * active_learning.get_samples).  Each entry point below names the reference interface it stands
+ * in for; INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every call returns 0 (DRL_OK) or a negative drl_status; the message is kept per context
+ *     (drl_last_error) — nothing throws or aborts across the ABI;
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe: one context per
+ *     GPU / per thread;
+ *   - "host" entry points take host pointers, copy in/out and return with outputs valid (the
+ *     blocking semantics of sess.run / Keras predict); "_dev" entry points take device pointers
+ *     on the context's GPU, enqueue on the context's stream and return without synchronising;
+ *   - there is no CPU fallback: without a usable GPU drl_create fails.
+ *
+ * Window indexing (reference env.py:153-169, myasp-A1.py:120-134): a series of N samples and
+ * window length W has K = N - W windows; window k belongs to cursor c = k + W.
+ *   LSTM state of window k : rows t = 0..W-1 = samples k+1+t (includes sample c), plus a flag channel
+ *   VAE window, vae_lag = 1: samples k .. k+W-1   (reference myasp-A1.py:139, excludes sample c)
+ *   VAE window, vae_lag = 0: samples k+1 .. k+W   (reference myasp-wadi.py:132-135 / penalty_array[c])
+ */
+#ifndef DRLVAE_H
+#define DRLVAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct drl_ctx drl_ctx;
+
+typedef enum drl_status {
+    DRL_OK = 0,
+    DRL_ERR_ARG = -1,         /* bad argument (null pointer, shape out of the supported range) */
+    DRL_ERR_HIP = -2,         /* a HIP runtime call failed; message holds hipGetErrorString */
+    DRL_ERR_STATE = -3,       /* weights not set / context unusable */
+    DRL_ERR_UNSUPPORTED = -4  /* shape outside what the kernels implement */
+} drl_status;
+
+/* activation codes of drl_set_vae */
+enum { DRL_ACT_LINEAR = 0, DRL_ACT_RELU = 1, DRL_ACT_SIGMOID = 2 };
+
+/* how the flag channel (last LSTM input feature) is filled */
+typedef enum drl_flag_mode {
+    DRL_FLAG_ZEROS = 0,     /* all zero */
+    DRL_FLAG_QUIRK = 1,     /* env.get_states_list(): a single 1 at row W-1-k for k < W
+                               (reference myasp-A1.py:126 shifted by env.py:160-168) */
+    DRL_FLAG_EXPLICIT = 2,  /* per-sample flags given by the caller: row t of window k carries
+                               flags[k+1+t] (teacher-forced action history, env.py:143-147) */
+    DRL_FLAG_BOTH = 3       /* two candidate states per window, flag column all 0 and all 1
+                               (reference myasp-wadi.py:248-254); q is [K,2,A] */
+} drl_flag_mode;
+
+typedef enum drl_action_rule {
+    DRL_ACTION_ARGMAX = 0,  /* np.argmax(Q), ties -> 0 (reference myasp-A1.py:226-227) */
+    DRL_ACTION_WADI = 1     /* 1 if Q(state a1)[1] > Q(state a0)[0] (reference myasp-wadi.py:328);
+                               needs DRL_FLAG_BOTH */
+} drl_action_rule;
+
+typedef struct drl_score_opts {
+    int32_t struct_size;     /* sizeof(drl_score_opts), for forward compatibility */
+    int32_t vae_lag;         /* 0 or 1, see "Window indexing" */
+    int32_t flag_mode;       /* drl_flag_mode */
+    int32_t action_rule;     /* drl_action_rule */
+    const float* flags;      /* DRL_FLAG_EXPLICIT: one flag per sample, laid out like the series
+                                (first feature stride), else NULL */
+    const float* eps;        /* optional N(0,1) draws [K_total, latent] for z = mu + exp(lv/2)*eps
+                                (reference myasp-A1.py:84); NULL = mean path z = mu */
+    const float* in_scale;   /* optional per-series MinMax scale_ [n_seg] (reference env.py:78-79:
+                                v = x*scale_ + min_, two float32 roundings); NULL = series is
+                                already normalised */
+    const float* in_offset;  /* per-series min_ [n_seg]; required iff in_scale */
+    const float* vae_center; /* optional RobustScaler center_ [W*F] (reference myasp-wadi.py:138) */
+    const float* vae_scale;  /* RobustScaler scale_ [W*F]; required iff vae_center */
+    float vae_clip;          /* clip of the scaled VAE input (myasp-wadi.py:139); <= 0 = none */
+    int32_t reserved;
+} drl_score_opts;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Creates a context on GPU `device_id` with its own stream.  Fails (DRL_ERR_HIP) when the device
+ * is not a usable gfx950 GPU. */
+int drl_create(int device_id, drl_ctx** out);
+void drl_destroy(drl_ctx* ctx);
+/* Message of the last failing call on ctx; with ctx == NULL the last drl_create failure of the
+ * calling thread.  Never NULL. */
+const char* drl_last_error(drl_ctx* ctx);
+/* Library version string. */
+const char* drl_version(void);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own;
+ * NULL restores the context's stream. */
+int drl_set_stream(drl_ctx* ctx, void* hip_stream);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int drl_synchronize(drl_ctx* ctx);
+
+/* ---- weights -------------------------------------------------------------------------------- */
+
+/* Replaces load_model('vae_model.h5', custom_objects={'Sampling': Sampling}) (reference
+ * myasp-A1.py:567) / build_vae (myasp-A1.py:87-101, myasp-wadi.py:101-117): a chain of Keras
+ * Dense layers y = act(x.K + b), K [in,out] row-major.  Layer order: encoder hidden..., mu,
+ * logvar, decoder...; dims has n_layers+1 entries for that *chain view* (dims[mu_layer+1] =
+ * dims[logvar_layer+1] = latent size, and the decoder starts from the latent).  Host pointers;
+ * copied and re-packed for the MFMA kernels. */
+int drl_set_vae(drl_ctx* ctx, int n_layers, const int32_t* in_dims, const int32_t* out_dims,
+                const int32_t* acts, int mu_layer, int logvar_layer,
+                const float* const* kernels, const float* const* biases, float logvar_clip);
+
+/* Replaces Q_Estimator_Nonlinear.__init__ + Saver.restore (reference myasp-A1.py:165-179,
+ * 313-319) / QNet.build (myasp-wadi.py:212-224): TF1 LSTMCell(hidden, forget_bias) under
+ * static_rnn with zero initial state, kernel [in_dim+hidden, 4*hidden] with gate column blocks
+ * i|j|f|o, followed by Q = h_T.w_out + b_out. */
+int drl_set_lstm(drl_ctx* ctx, int in_dim, int hidden, int n_actions, float forget_bias,
+                 const float* kernel, const float* bias, const float* w_out, const float* b_out);
+
+/* ---- the fused path ------------------------------------------------------------------------- */
+
+/* Scores every sliding window of n_seg independent series (windows never cross a series).
+ * Replaces, per window, env.rewardfnc's vae.predict + np.mean(np.square(..)) (reference
+ * myasp-A1.py:139-141; batched form myasp-wadi.py:143-146), env.statefnc + estimator.predict
+ * (myasp-A1.py:120-134, 197-199, 254), np.argmax / the WaDi rule (myasp-A1.py:227,
+ * myasp-wadi.py:328) and the AL margin |q0-q1| (myasp-A1.py:255).
+ *
+ *   series      [total_samples, F] row-major, series i occupies samples seg_offsets[i] ..
+ *               seg_offsets[i+1]-1 (seg_offsets has n_seg+1 entries, host memory in both variants)
+ *   outputs     concatenated per series, K_i = max(0, N_i - W) windows each:
+ *               recon_err [K_total], q [K_total, S, A] (S = 2 for DRL_FLAG_BOTH else 1),
+ *               action [K_total] int32, margin [K_total]; any output pointer may be NULL.
+ *               The margin is |q[0]-q[1]| (argmax rule) or |Q(a1)[1]-Q(a0)[0]| (WaDi rule).
+ * drl_score_batch: every data pointer is host memory; synchronous.
+ * drl_score_batch_dev: series / opts->flags / opts->eps / outputs are device pointers (the small
+ * per-series and per-column option arrays stay host pointers); asynchronous on the stream. */
+int drl_score_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg,
+                    int F, int W, const drl_score_opts* opts,
+                    float* recon_err, float* q, int32_t* action, float* margin);
+int drl_score_batch_dev(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg,
+                        int F, int W, const drl_score_opts* opts,
+                        float* recon_err, float* q, int32_t* action, float* margin);
+/* One series: drl_score_batch with n_seg = 1. */
+int drl_score_series(drl_ctx* ctx, const float* series, int64_t N, int F, int W,
+                     const drl_score_opts* opts,
+                     float* recon_err, float* q, int32_t* action, float* margin);
+
+/* ---- call-surface compatibility (explicit batches, host pointers, synchronous) --------------- */
+
+/* vae.predict(x) (reference myasp-A1.py:140, myasp-wadi.py:145): x [B,D] -> reconstruction
+ * [B,D]; recon_err [B] (optional) = mean((recon-x)^2, axis=1); eps optional [B,latent]. */
+int drl_vae_predict(drl_ctx* ctx, const float* x, int64_t B, const float* eps,
+                    float* recon, float* recon_err);
+/* estimator.predict(state) (reference myasp-A1.py:197-199, myasp-wadi.py:228-229):
+ * states [B,W,in_dim] -> q [B,A]. */
+int drl_q_predict(drl_ctx* ctx, const float* states, int64_t B, int W, float* q);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* With profiling on, every kernel launch of the scoring path is bracketed by hipEvents on the
+ * launch stream; drl_profile_read synchronises and returns accumulated milliseconds and launch
+ * counts since the last drl_profile_reset.  which: 0 = LSTM kernel, 1 = VAE kernel. */
+int drl_profile_enable(drl_ctx* ctx, int on);
+int drl_profile_reset(drl_ctx* ctx);
+int drl_profile_read(drl_ctx* ctx, int which, double* total_ms, int64_t* launches);
+/* Name of the LSTM kernel variant the last scoring call used ("h128i2" or "generic"). */
+const char* drl_last_lstm_variant(drl_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRLVAE_H */

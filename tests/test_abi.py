@@ -1,0 +1,44 @@
+"""CPU-only: libdrlvae.so loads, exports every symbol include/drlvae.h declares, and the struct
+layout the Python side uses matches the header.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "drlvae.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    from drlvae import _abi
+    lib = _abi.load()
+    declared = set(re.findall(r"\b(drl_[a-z0-9_]+)\s*\(", _header()))
+    assert declared == set(_abi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.drl_version()
+
+
+def test_opts_struct_layout_matches_header():
+    from drlvae import _abi
+    body = re.search(r"typedef struct drl_score_opts \{(.*?)\} drl_score_opts;", _header(), re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(?:const\s+)?(int32_t|float)\s*(\*?)\s*(\w+)\s*;", body)
+    assert [f[2] for f in fields] == [n for n, _ in _abi.ScoreOpts._fields_]
+    for (typ, star, name), (_, ctype) in zip(fields, _abi.ScoreOpts._fields_):
+        want = C.c_void_p if star else {"int32_t": C.c_int32, "float": C.c_float}[typ]
+        assert ctype is want, name
+    assert C.sizeof(_abi.ScoreOpts) == 72
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from drlvae.scorer import WindowScorer
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device|failed"):
+        WindowScorer(0)

@@ -1,0 +1,277 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle on the same inputs.
+
+Tolerance (BASELINE.json north_star): reconstruction error and Q-values within 1e-5 relative
+(fp32); window indices and actions bit-exact.  An action can only differ from the oracle's where
+|q0-q1| is below the Q tolerance itself, so actions are asserted exact wherever the oracle's margin
+exceeds 2e-5*max|Q| and the sub-margin count is asserted tiny.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_model_npz
+from oracle import ref_path as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+W = 25
+
+
+@pytest.fixture(scope="module")
+def scorer():
+    from drlvae.scorer import WindowScorer
+    s = WindowScorer(0)
+    yield s
+    s.close()
+
+
+def assert_q_close(got, want, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = np.maximum(np.abs(want), np.abs(want).max(axis=-1, keepdims=True))
+    rel = np.abs(got - want) / scale
+    assert rel.max() <= RTOL, f"{what}: max rel diff {rel.max():.3e}"
+
+
+def assert_actions(got, q_want, act_want):
+    q_want = np.asarray(q_want, np.float64)
+    margin = np.abs(q_want[..., 0] - q_want[..., 1])
+    safe = margin > 2 * RTOL * np.abs(q_want).max(axis=-1)
+    assert np.array_equal(np.asarray(got)[safe], np.asarray(act_want)[safe])
+    assert (~safe).sum() <= max(2, len(safe) // 1000)
+
+
+def synth_lstm(rng, I, H, A=2):
+    lim = np.sqrt(6.0 / (I + H + 4 * H))
+    return {"kernel": rng.uniform(-lim, lim, (I + H, 4 * H)).astype(np.float32),
+            "bias": rng.uniform(-0.1, 0.1, 4 * H).astype(np.float32),
+            "w_out": rng.normal(0, 1, (H, A)).astype(np.float32),
+            "b_out": rng.normal(0, 1, A).astype(np.float32)}
+
+
+def synth_vae(rng, dims, mu_layer):
+    """dims: chain view e.g. [D,128,10,128,D] -> layers enc..., mu, logvar, dec..."""
+    ks, bs, acts = [], [], []
+    chain = []
+    for i in range(len(dims) - 1):
+        chain.append((dims[i], dims[i + 1]))
+    layers = []
+    for i, (a, b) in enumerate(chain):
+        layers.append((a, b, "hidden"))
+        if i == mu_layer:
+            layers[-1] = (a, b, "mu")
+            layers.append((a, b, "logvar"))
+    for n, (a, b, kind) in enumerate(layers):
+        lim = np.sqrt(6.0 / (a + b))
+        ks.append(rng.uniform(-lim, lim, (a, b)).astype(np.float32))
+        bs.append(rng.uniform(-0.05, 0.05, b).astype(np.float32))
+        acts.append(0 if kind in ("mu", "logvar") else 1)
+    acts[-1] = 2
+    return {"kernels": ks, "biases": bs, "acts": acts, "mu_layer": mu_layer,
+            "logvar_layer": mu_layer + 1, "logvar_clip": 10.0}
+
+
+# ----------------------------------------------------------------------------------- C1
+def test_c1_real1_quirk(scorer, a1, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    v = a1["series"][0]
+    out = scorer.score(v, W, flag_mode="quirk")
+    assert scorer.lstm_variant == "h128i2"
+    exp = np.load(os.path.join(GOLDEN, "c1_expected.npz"))
+    assert out["err"].shape == (1395,) and out["q"].shape == (1395, 2)
+    np.testing.assert_allclose(out["err"], exp["err_f64"], rtol=RTOL)
+    np.testing.assert_allclose(out["err"], exp["err_f32"], rtol=RTOL)
+    assert_q_close(out["q"], exp["q_f64"], "q vs fp64 oracle")
+    assert_q_close(out["q"], exp["q_f32"], "q vs fp32 oracle")
+    assert_actions(out["action"], exp["q_f64"], exp["action_f64"])
+    np.testing.assert_allclose(out["margin"], np.abs(out["q"][:, 0] - out["q"][:, 1]), rtol=0, atol=0)
+    assert np.array_equal(out["action"], (out["q"][:, 1] > out["q"][:, 0]).astype(np.int32))
+
+
+def test_c1_zeros_and_explicit_flags(scorer, a1, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    v = a1["series"][0]
+    exp = np.load(os.path.join(GOLDEN, "c1_expected.npz"))
+    out = scorer.score(v, W, flag_mode="zeros", want=("q",))
+    assert_q_close(out["q"], exp["q_zeros_f64"], "zeros")
+    # teacher-forced action history: flags per sample
+    rng = np.random.default_rng(5)
+    acts = (rng.random(len(v) - W) < 0.3).astype(np.int32)
+    S = orc.states_teacher_forced(v, W, acts)
+    flags = np.zeros(len(v), np.float32)
+    flags[W] = 1.0
+    flags[W + 1:] = acts[:-1]
+    want = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64)
+    out = scorer.score(v, W, flag_mode="explicit", flags=flags, want=("q",))
+    assert_q_close(out["q"], want, "explicit flags")
+
+
+def test_c1_vae_model_h5_variant(scorer, a1):
+    _, vae = load_model_npz("vae_model_h5.npz")
+    scorer.set_vae(vae)
+    out = scorer.score(a1["series"][0], W, want=("err",))
+    exp = np.load(os.path.join(GOLDEN, "c1_expected.npz"))
+    np.testing.assert_allclose(out["err"], exp["err_h5_f64"], rtol=RTOL)
+
+
+def test_device_side_minmax_is_bit_exact(scorer, a1, ckpt_a1):
+    """K1: x*scale_ + min_ on the device reproduces sklearn's float32 result bit for bit, so
+    scoring raw values with (scale, offset) equals scoring the reference-normalised series."""
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    raws = a1["raw3"]
+    off = np.concatenate([[0], np.cumsum([len(r) for r in raws])])
+    sc, of = zip(*[orc.minmax_f32(r)[1:] for r in raws])
+    a = scorer.score(np.concatenate(raws), W, off, in_scale=np.array(sc), in_offset=np.array(of))
+    b = scorer.score(np.concatenate(a1["series"][:3]), W, off)
+    for k in ("err", "q", "action", "margin"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+# ----------------------------------------------------------------------------------- C2
+def test_c2_all_a1_series_ragged_batch(scorer, a1, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    series = a1["series"]
+    off = np.concatenate([[0], np.cumsum([len(s) for s in series])])
+    out = scorer.score(np.concatenate(series), W, off, flag_mode="quirk")
+    K = sum(len(s) - W for s in series)
+    assert K == 93191 and out["err"].shape == (K,)
+    pos = 0
+    n_unsafe = 0
+    for s in series:
+        r = orc.score_series_univariate(s, W, vae, lstm, "quirk", dtype=np.float64)
+        k = len(s) - W
+        np.testing.assert_allclose(out["err"][pos:pos + k], r["err"], rtol=RTOL)
+        assert_q_close(out["q"][pos:pos + k], r["q"])
+        margin = np.abs(r["q"][:, 0] - r["q"][:, 1])
+        safe = margin > 2 * RTOL * np.abs(r["q"]).max(axis=1)
+        n_unsafe += int((~safe).sum())
+        assert np.array_equal(out["action"][pos:pos + k][safe], r["action"][safe])
+        pos += k
+    assert n_unsafe <= 20
+    # AL ranking (reference myasp-A1.py:250-259) from device margins, first series
+    k0 = len(series[0]) - W
+    r0 = orc.score_series_univariate(series[0], W, vae, lstm, "quirk", dtype=np.float32)
+    mine = np.argsort(out["margin"][:k0])[:20]
+    theirs = np.argsort(r0["margin"])[:20]
+    assert len(set(mine) & set(theirs)) >= 18
+
+
+def test_edge_cases_ragged_short_series(scorer, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    rng = np.random.default_rng(11)
+    lens = [W + 1, 10, W, W + 64, W + 65, 0, W + 127, W + 33]        # 1, 0, 0, 64, 65, 0, 127, 33 windows
+    series = [rng.random(n).astype(np.float32) for n in lens]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    out = scorer.score(np.concatenate(series), W, off, flag_mode="quirk")
+    want_k = sum(max(0, n - W) for n in lens)
+    assert out["err"].shape == (want_k,)
+    pos = 0
+    for s in series:
+        k = max(0, len(s) - W)
+        if k == 0:
+            continue
+        r = orc.score_series_univariate(s, W, vae, lstm, "quirk", dtype=np.float64)
+        np.testing.assert_allclose(out["err"][pos:pos + k], r["err"], rtol=RTOL)
+        assert_q_close(out["q"][pos:pos + k], r["q"])
+        pos += k
+    # nothing to score at all: outputs stay empty, no error
+    e = scorer.score(rng.random(W).astype(np.float32), W)
+    assert e["err"].shape == (0,)
+
+
+# ----------------------------------------------------------------------------------- call surface
+def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    v = a1["series"][3]
+    S = orc.states_list_univariate(v, W)[:300]
+    q = scorer.q_predict(S)
+    assert scorer.lstm_variant == "generic"
+    assert_q_close(q, orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
+    one = scorer.q_predict(S[:1])                       # the reference's batch-1 call pattern
+    assert np.array_equal(one, q[:1])
+    X = orc.vae_windows_univariate(v, W)[:100]
+    rec, err = scorer.vae_predict(X, return_err=True)
+    want = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
+                           dtype=np.float64)
+    np.testing.assert_allclose(rec, want, rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(err, orc.recon_error(X, want, np.float64), rtol=RTOL)
+    # the reference's sampling path with explicit noise
+    eps = np.random.default_rng(2).normal(size=(100, 10)).astype(np.float32)
+    rec = scorer.vae_predict(X, eps=eps)
+    want = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
+                           eps=eps, dtype=np.float64)
+    np.testing.assert_allclose(rec, want, rtol=RTOL, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------- multivariate
+@pytest.mark.parametrize("F,H,N", [(3, 64, 300), (38, 64, 700), (38, 128, 260), (123, 64, 400)])
+def test_multivariate_wadi_formulation(scorer, F, H, N):
+    rng = np.random.default_rng(F * 1000 + H)
+    x = rng.random((N, F), dtype=np.float32)
+    if F == 123:                                        # C4: per-sensor scales, heavy tails
+        x = (rng.normal(size=(N, F)) * rng.uniform(0.1, 100, F)).astype(np.float32)
+    D = W * F
+    vae = synth_vae(rng, [D, 128, 10, 128, D], 1)
+    lstm = synth_lstm(rng, F + 1, H)
+    if F == 123:
+        lstm["kernel"][:F] *= 0.01                      # keep the gates out of saturation on raw sensors
+    sample = rng.choice(np.arange(W, N), size=min(200, N - W), replace=False)
+    wins = np.array([x[i - W + 1:i + 1].reshape(-1) for i in sample])
+    center, scale = orc.robust_scaler_fit(wins)
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    out = scorer.score(x, W, vae_lag=0, flag_mode="both", action_rule="wadi",
+                       vae_center=center, vae_scale=scale, vae_clip=10.0)
+    assert scorer.lstm_variant == "generic"
+    want = orc.score_series_multivariate(x, W, vae, lstm, center, scale, 10.0, dtype=np.float64)
+    assert out["q"].shape == (N - W, 2, 2)
+    np.testing.assert_allclose(out["err"], want["err"], rtol=RTOL)
+    assert_q_close(out["q"], want["q"])
+    m = np.abs(want["q"][:, 1, 1] - want["q"][:, 0, 0])
+    safe = m > 2 * RTOL * np.abs(want["q"]).max(axis=(1, 2))
+    assert np.array_equal(out["action"][safe], want["action"][safe])
+    np.testing.assert_allclose(out["margin"], np.abs(out["q"][:, 1, 1] - out["q"][:, 0, 0]), rtol=0, atol=0)
+
+
+def test_window_50_univariate(scorer):
+    """C5 shape: W = 50, VAE [50,64,64,64,10,64,50], LSTM I2/H128."""
+    rng = np.random.default_rng(50)
+    v = rng.random(50 + 333, dtype=np.float32)
+    vae = synth_vae(rng, [50, 64, 64, 64, 10, 64, 50], 3)
+    lstm = synth_lstm(rng, 2, 128)
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    out = scorer.score(v, 50, flag_mode="zeros")
+    assert scorer.lstm_variant == "h128i2"
+    want = orc.score_series_univariate(v, 50, vae, lstm, "zeros", dtype=np.float64)
+    np.testing.assert_allclose(out["err"], want["err"], rtol=RTOL)
+    assert_q_close(out["q"], want["q"])
+
+
+def test_errors_are_reported_not_crashed(scorer, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    with pytest.raises(RuntimeError, match="W\\*F"):
+        scorer.score(np.zeros(100, np.float32), 30)     # VAE is 25 wide
+    with pytest.raises(RuntimeError, match="WaDi"):
+        scorer.score(np.zeros(100, np.float32), W, action_rule="wadi")
+    bad = dict(lstm)
+    bad["kernel"] = np.zeros((2 + 130, 4 * 130), np.float32)
+    bad["bias"] = np.zeros(4 * 130, np.float32)
+    bad["w_out"] = np.zeros((130, 2), np.float32)
+    with pytest.raises(RuntimeError, match="hidden"):
+        scorer.set_lstm(bad)
