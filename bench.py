@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Throughput of the window-scoring path (VAE reward + LSTM-DQN Q / action / margin per window).
+
+One "step" = one pass of the hot path over one batch of synthetic series resident in HBM
+(drl_score_batch_dev).  With N > 1 ranks (torchrun, one process per GPU) every rank scores its own
+batch of the same shape (weak scaling, windows are independent) and the per-window scores are
+all-gathered over RCCL, the only collective of the path.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dynamic-reward-rl-vae_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk
+
+
+def glorot(rng, a, b):
+    lim = np.sqrt(6.0 / (a + b))
+    return rng.uniform(-lim, lim, (a, b)).astype(np.float32)
+
+
+def make_vae(rng, chain, mu_pos):
+    """chain e.g. [25,64,64,64,10,64,25]; layer mu_pos maps to the latent."""
+    ks, bs, acts = [], [], []
+    for i in range(len(chain) - 1):
+        ks.append(glorot(rng, chain[i], chain[i + 1]))
+        bs.append(np.zeros(chain[i + 1], np.float32))
+        acts.append(1)
+        if i == mu_pos:
+            acts[-1] = 0
+            ks.append(glorot(rng, chain[i], chain[i + 1]))
+            bs.append(np.zeros(chain[i + 1], np.float32))
+            acts.append(0)
+    acts[-1] = 2
+    return {"kernels": ks, "biases": bs, "acts": acts, "mu_layer": mu_pos, "logvar_layer": mu_pos + 1,
+            "logvar_clip": 10.0}
+
+
+def make_lstm(rng, I, H, A=2):
+    return {"kernel": glorot(rng, I + H, 4 * H), "bias": np.zeros(4 * H, np.float32),
+            "w_out": glorot(rng, H, A), "b_out": np.zeros(A, np.float32), "forget_bias": 1.0}
+
+
+def a1_lengths():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "a1_series.npz"))
+    return np.diff(z["offsets"]).astype(np.int64)
+
+
+def workload(name, rank, windows):
+    """Shapes of SURVEY.md §8(d).  Returns dict(series [N,F] float32, offsets, W, F, vae, lstm, opts)."""
+    rng_w = np.random.default_rng(1234)
+    if name in ("c1", "c2"):
+        W, F, H = 25, 1, 128
+        lens = a1_lengths() if name == "c2" else a1_lengths()[:1]
+        rng = np.random.default_rng(100 + rank)
+        series = rng.random((int(lens.sum()), 1), dtype=np.float32)
+        vae = make_vae(rng_w, [25, 64, 64, 64, 10, 64, 25], 3)
+        desc = ("C2: 67 synthetic series with the Yahoo A1 lengths (93,191 windows), W=25, univariate, "
+                "VAE 25-64-64-64-10-64-25 + LSTM I2/H128" if name == "c2" else
+                "C1: one synthetic series of real_1's length (1,395 windows), W=25")
+        kw = dict(vae_lag=1, flag_mode="quirk", action_rule="argmax")
+    elif name == "c5":
+        W, F, H = 50, 1, 128
+        n = int(windows) + W
+        rng = np.random.default_rng(50 + rank)
+        series = rng.random((n, 1), dtype=np.float32)
+        lens = np.array([n])
+        vae = make_vae(rng_w, [50, 64, 64, 64, 10, 64, 50], 3)
+        desc = f"C5: one synthetic univariate stream of {int(windows):,} windows per GPU, W=50, LSTM I2/H128"
+        kw = dict(vae_lag=1, flag_mode="zeros", action_rule="argmax")
+    elif name in ("c3", "c4"):
+        W = 25
+        F, n, seed = (38, 28479, 38) if name == "c3" else (123, int(windows) + W if windows else 172801, 123)
+        H = 64
+        rng = np.random.default_rng(seed + rank)
+        if name == "c3":
+            series = rng.random((n, F), dtype=np.float32)
+        else:
+            series = (rng.standard_normal((n, F), dtype=np.float32) *
+                      rng.uniform(0.1, 100, F).astype(np.float32))
+        lens = np.array([n])
+        vae = make_vae(rng_w, [W * F, 128, 10, 128, W * F], 1)
+        samp = rng.choice(np.arange(W, n), 200, replace=False)
+        wins = np.stack([series[i - W + 1:i + 1].reshape(-1) for i in samp]).astype(np.float64)
+        center = np.median(wins, axis=0)
+        q = np.percentile(wins, [25, 75], axis=0)
+        scale = q[1] - q[0]
+        scale[scale == 0] = 1.0
+        desc = (f"{name.upper()}: synthetic {F}-sensor stream, N={n:,}, W=25, VAE {W*F}-128-10-128-{W*F}, "
+                f"LSTM I{F+1}/H64, two candidate states per window")
+        kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=center, vae_scale=scale,
+                  vae_clip=10.0)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    lstm = make_lstm(rng_w, F + 1, H)
+    if name == "c4":
+        lstm["kernel"][:F] *= 0.01
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    S = 2 if kw["flag_mode"] == "both" else 1
+    chain = [k.shape[0] for i, k in enumerate(vae["kernels"]) if i != vae["logvar_layer"]] + [W * F]
+    vae_flops = 2 * sum(chain[i] * chain[i + 1] for i in range(len(chain) - 1))
+    lstm_flops = S * (2 * W * (F + 1 + H) * 4 * H + 2 * H * 2)
+    return dict(name=name, desc=desc, series=series, offsets=offsets, W=W, F=F, H=H, S=S, vae=vae, lstm=lstm,
+                kw=kw, vae_flops=vae_flops, lstm_flops=lstm_flops,
+                K=int(np.maximum(lens - W, 0).sum()))
+
+
+def cpu_baseline(wl):
+    """The oracle (numpy fp32 restatement of the reference's path, batched per series) timed on
+    the host cores of this box on a bounded sample of the same workload."""
+    from oracle import ref_path as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    W, F = wl["W"], wl["F"]
+    x, off = wl["series"], wl["offsets"]
+    budget = 15.0
+    done = 0
+    t0 = time.perf_counter()
+    for i in range(len(off) - 1):
+        s = x[off[i]:off[i + 1]]
+        if F == 1:
+            n = min(len(s), 3000 + W)
+            orc.score_series_univariate(s[:n, 0], W, wl["vae"], wl["lstm"],
+                                        "quirk" if wl["kw"]["flag_mode"] == "quirk" else "zeros")
+        else:
+            n = min(len(s), 600 + W)
+            orc.score_series_multivariate(s[:n], W, wl["vae"], wl["lstm"], wl["kw"]["vae_center"],
+                                          wl["kw"]["vae_scale"], 10.0)
+        done += max(0, n - W)
+        if time.perf_counter() - t0 > budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "windows/s", "cores": int(cores), "kind": "port",
+            "sample": f"first {done:,} windows of the same workload, oracle/ref_path.py (numpy fp32, "
+                      f"whole-series batches, not the reference's TF path which cannot run here), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--windows", type=float, default=0, help="windows per GPU for c5 (default 4e6) / c4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "c5" and not args.windows:
+        args.windows = 4e6
+    wl = workload(args.workload, rank, args.windows)
+    from drlvae.scorer import WindowScorer
+    sc = WindowScorer(local)
+    sc.set_vae(wl["vae"])
+    sc.set_lstm(wl["lstm"])
+    stream = torch.cuda.Stream(device=dev)
+    sc.set_stream(stream.cuda_stream)
+
+    K, S = wl["K"], wl["S"]
+    with torch.cuda.stream(stream):
+        series = torch.from_numpy(wl["series"]).to(dev)
+        out = {"err": torch.empty(K, dtype=torch.float32, device=dev),
+               "q": torch.empty((K, S, 2), dtype=torch.float32, device=dev),
+               "action": torch.empty(K, dtype=torch.int32, device=dev),
+               "margin": torch.empty(K, dtype=torch.float32, device=dev)}
+        gathered = None
+        if world > 1 and not args.no_allgather:
+            gathered = {k: torch.empty((world,) + tuple(v.shape), dtype=v.dtype, device=dev) for k, v in out.items()}
+    stream.synchronize()
+
+    def step():
+        sc.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
+        if gathered is not None:
+            with torch.cuda.stream(stream):
+                for k in out:
+                    dist.all_gather_into_tensor(gathered[k], out[k])
+
+    def fence():
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    sc.profile(True)
+    sc.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    lstm_ms, lstm_n = sc.profile_read(0)
+    vae_ms, vae_n = sc.profile_read(1)
+    sc.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_windows = K * world * args.steps
+        lstm_avg_s = lstm_ms / max(lstm_n, 1) / 1e3
+        achieved = wl["lstm_flops"] * K / lstm_avg_s / 1e12 if lstm_n else 0.0
+        res = {
+            "metric": "windows scored/sec (VAE reward + LSTM Q)",
+            "value": total_windows / dt,
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "windows_per_gpu_per_step": K, "window": wl["W"],
+                       "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
+                       "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
+                       "collective": "rccl all_gather of err/q/action/margin" if gathered is not None else "none",
+                       "lstm_kernel": sc.lstm_variant},
+            "roofline": {"bound": "mfma", "kernel": "lstm_" + sc.lstm_variant,
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": lstm_avg_s * 1e3, "launches": lstm_n,
+                         "flop_per_launch": wl["lstm_flops"] * K,
+                         "vae_kernel_avg_ms": vae_ms / max(vae_n, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sc.close()
+
+
+if __name__ == "__main__":
+    main()
