@@ -425,25 +425,32 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
         return unit < H ? gate * H + unit : -1;
     };
     const size_t ld = 4 * (size_t)H;
+    // Gate pre-activations leave the MFMAs already scaled for v_exp_f32 (2^x): i|f|o by -log2(e),
+    // j by -2*log2(e); forget_bias joins the f bias (TF adds it before the sigmoid,
+    // reference myasp-A1.py:177 LSTMCell(forget_bias=1.0)).
+    const double L2E = 1.4426950408889634;
+    auto gscale = [&](int i) -> double { return (i & 3) == 1 ? -2.0 * L2E : -L2E; };
     for (int ks = 0; ks < nks; ++ks)
         for (int tau = 0; tau < NT; ++tau)
             for (int ln = 0; ln < 64; ++ln) {
                 const int feat = 2 * ks + (ln >> 5), cc = col(tau, ln & 31);
                 pack[l.wx_off + ((size_t)ks * NT + tau) * 64 + ln] =
-                    (feat < in_dim && cc >= 0) ? kernel[(size_t)feat * ld + cc] : 0.0f;
+                    (feat < in_dim && cc >= 0) ? (float)(gscale(ln & 31) * kernel[(size_t)feat * ld + cc]) : 0.0f;
             }
     for (int kk = 0; kk < NT * 4; ++kk)
         for (int tau = 0; tau < NT; ++tau)
             for (int ln = 0; ln < 64; ++ln) {
                 const int unit = 8 * (kk >> 2) + 2 * (kk & 3) + (ln >> 5), cc = col(tau, ln & 31);
                 pack[l.u_off + ((size_t)kk * NT + tau) * 64 + ln] =
-                    (unit < H && cc >= 0) ? kernel[(size_t)(in_dim + unit) * ld + cc] : 0.0f;
+                    (unit < H && cc >= 0) ? (float)(gscale(ln & 31) * kernel[(size_t)(in_dim + unit) * ld + cc]) : 0.0f;
             }
     for (int tau = 0; tau < NT; ++tau)
         for (int half = 0; half < 2; ++half)
             for (int r = 0; r < 16; ++r) {
-                const int cc = col(tau, rowmap_h(r, half));
-                pack[l.bias_off + (tau * 2 + half) * 16 + r] = cc >= 0 ? bias[cc] : 0.0f;
+                const int i = rowmap_h(r, half), cc = col(tau, i);
+                const double fbias = (i & 3) == 2 ? (double)forget_bias : 0.0;
+                pack[l.bias_off + (tau * 2 + half) * 16 + r] =
+                    cc >= 0 ? (float)(gscale(i) * ((double)bias[cc] + fbias)) : 0.0f;
             }
     for (int u = 0; u < H; ++u)
         for (int a = 0; a < n_actions; ++a) pack[l.wout_off + (size_t)u * n_actions + a] = w_out[(size_t)u * n_actions + a];

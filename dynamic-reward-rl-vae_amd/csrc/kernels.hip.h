@@ -26,6 +26,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// Pins a stationary weight into the accumulator half of the register file.  hipcc otherwise
+// treats AGPRs as spill space and copies every such weight back with v_accvgpr_read in front of
+// its MFMA, and on gfx950 every VALU instruction adds to the fp32 MFMA time (they do not overlap:
+// tools/ubench_mfma_valu.hip).  A value *defined* in register class "a" stays there, and the MFMA
+// builtin takes an AGPR as its A operand directly (AV operand), with the compiler still in charge
+// of every hazard.
+__device__ __forceinline__ float pin_agpr(float x) {
+    float r;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(x));
+    return r;
+}
+
 // sigmoid / tanh through v_exp_f32 + v_rcp_f32 (both 1 ulp): absolute error ~1e-7.
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -273,10 +285,18 @@ __device__ __forceinline__ float synth_flag(int mode, long long k, int t, int W,
     return 0.0f;
 }
 
-// One LSTM cell update for the four gate registers of one (unit, window).
+// One LSTM cell update for the four gate registers of one (unit, window).  The gate
+// pre-activations arrive pre-scaled (pack_lstm in drlvae.hip multiplies the i|f|o columns by
+// -log2(e), the j columns by -2*log2(e), and folds forget_bias into the f bias), so each gate is
+// one v_exp_f32 + one v_rcp_f32:  sigmoid(z) = 1/(1+2^z'),  tanh(z) = 2/(1+2^z') - 1.
 __device__ __forceinline__ float lstm_cell(float zi, float zj, float zf, float zo, float fb, float& c) {
-    c = fast_sigmoid(zf + fb) * c + fast_sigmoid(zi) * fast_tanh(zj);
-    return fast_sigmoid(zo) * fast_tanh(c);
+    (void)fb;
+    const float si = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zi));
+    const float tj = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zj)), -1.0f);
+    const float sf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zf));
+    const float so = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
+    c = fmaf(sf, c, si * tj);
+    return so * fast_tanh(c);
 }
 
 // Generic shapes: one wave = 32 windows of one candidate state, weights streamed from L2 in
@@ -374,9 +394,12 @@ __global__ __launch_bounds__(256, 1) void lstm_generic_kernel(LstmArgs a) {
 // apart: while the MFMAs of one group run, the gate non-linearities of the other group issue on
 // the VALU of the same wave.
 #define H128_SV 256
-__device__ __forceinline__ void h128_gemm(f32x16 (&acc)[4], const float (&U)[4][64], const float (&wx)[4],
-                                          const float* __restrict__ hb, const float* __restrict__ bias_l,
-                                          float bx, int lane, int half, int w) {
+#ifndef H128_UREG
+#define H128_UREG 3     // gate tiles (of 4 per wave) whose recurrent weights sit in AGPRs; the rest in LDS
+#endif
+__device__ __forceinline__ void h128_gemm(f32x16 (&acc)[4], const float (&U)[H128_UREG][64], const float (&wx)[4],
+                                          const float* __restrict__ ul, const float* __restrict__ hb,
+                                          const float* __restrict__ bias_l, float bx, int lane, int half, int w) {
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) {
         acc[tl] = load_bias16(bias_l, 4 * w + tl, half);
@@ -386,7 +409,9 @@ __device__ __forceinline__ void h128_gemm(f32x16 (&acc)[4], const float (&U)[4][
     for (int kk = 0; kk < 64; ++kk) {
         const float b = hb[kk * 64 + lane];
 #pragma unroll
-        for (int tl = 0; tl < 4; ++tl) acc[tl] = mfma32(U[tl][kk], b, acc[tl]);
+        for (int tl = 0; tl < H128_UREG; ++tl) acc[tl] = mfma32(U[tl][kk], b, acc[tl]);
+#pragma unroll
+        for (int tl = H128_UREG; tl < 4; ++tl) acc[tl] = mfma32(ul[((tl - H128_UREG) * 64 + kk) * 64 + lane], b, acc[tl]);
     }
 }
 
@@ -399,23 +424,43 @@ __device__ __forceinline__ void h128_xonly(f32x16 (&acc)[4], const float (&wx)[4
     }
 }
 
+#ifndef H128_PW_FENCE
+#define H128_PW_FENCE 1
+#endif
 __device__ __forceinline__ void h128_pointwise(const f32x16 (&acc)[4], float (&c)[4][4], float* __restrict__ hb,
                                                float fb, int lane, int w) {
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
+    for (int tl = 0; tl < 4; ++tl) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const float hv = lstm_cell(acc[tl][4 * qd], acc[tl][4 * qd + 1], acc[tl][4 * qd + 2],
                                        acc[tl][4 * qd + 3], fb, c[tl][qd]);
             hb[((4 * w + tl) * 4 + qd) * 64 + lane] = hv;
+#if H128_PW_FENCE == 2
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+#if H128_PW_FENCE == 1
+        __builtin_amdgcn_sched_barrier(0);      // bound the live temporaries: one gate tile at a time
+#endif
+    }
 }
+
+#ifndef H128_ABL
+#define H128_ABL 0        // timing-only ablations (wrong results): 2 no barriers
+#endif
+#if H128_ABL == 2
+#define H128_SYNC() do { } while (0)
+#else
+#define H128_SYNC() __syncthreads()
+#endif
 
 __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
     // separate objects so that alias analysis can tell group A's h from group B's
     __shared__ __attribute__((aligned(16))) float s_hA[64 * 64];   // [k-step][lane]
     __shared__ __attribute__((aligned(16))) float s_hB[64 * 64];
     __shared__ __attribute__((aligned(16))) float s_bias[16 * 2 * 16];
+    __shared__ __attribute__((aligned(16))) float s_u[4][(4 - H128_UREG) * 64 * 64 + 4];   // per wave: U of its last tile(s)
     __shared__ float s_sv[H128_SV];          // normalised samples k0 .. k0+64+W
     __shared__ float s_sf[H128_SV];          // explicit flags of those samples
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -447,13 +492,17 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
     }
 
     // weights to registers
-    float U[4][64], wx[4];
+    float U[H128_UREG][64], wx[4];
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl) {
-        wx[tl] = a.wx[(4 * w + tl) * 64 + lane];
+    for (int tl = 0; tl < 4; ++tl) wx[tl] = a.wx[(4 * w + tl) * 64 + lane];
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) U[tl][kk] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
-    }
+    for (int tl = 0; tl < H128_UREG; ++tl)
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) U[tl][kk] = pin_agpr(a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane]);
+    float* ul = &s_u[w][0];
+    for (int tl = H128_UREG; tl < 4; ++tl)
+        for (int kk = 0; kk < 64; ++kk)
+            ul[((tl - H128_UREG) * 64 + kk) * 64 + lane] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
     __syncthreads();
 
     const float* bias_l = s_bias;
@@ -484,13 +533,13 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
         // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
         const float bxa = xin(0, t);
         h128_pointwise(accB, cB, hB, fb, lane, w);
-        h128_gemm(accA, U, wx, hA, bias_l, bxa, lane, half, w);
-        __syncthreads();
+        h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
+        H128_SYNC();
         // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
         const float bxb = xin(1, t);
         h128_pointwise(accA, cA, hA, fb, lane, w);
-        h128_gemm(accB, U, wx, hB, bias_l, bxb, lane, half, w);
-        __syncthreads();
+        h128_gemm(accB, U, wx, ul, hB, bias_l, bxb, lane, half, w);
+        H128_SYNC();
     }
     h128_pointwise(accB, cB, hB, fb, lane, w);
     __syncthreads();

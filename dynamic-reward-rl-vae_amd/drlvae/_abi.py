@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrlvae.so")
+# DRLVAE_LIB points experiments (ablation builds) at another build of the same library
+LIB_PATH = os.environ.get("DRLVAE_LIB") or os.path.join(_HERE, "libdrlvae.so")
 
 FLAG_ZEROS, FLAG_QUIRK, FLAG_EXPLICIT, FLAG_BOTH = 0, 1, 2, 3
 ACTION_ARGMAX, ACTION_WADI = 0, 1

@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference's call surface for the scored path.
+
+A maintainer of the reference swaps the imports and keeps calling
+``vae.predict(x)``, ``estimator.predict(state=[s], sess=sess)``, ``env.statefnc`` /
+``env.rewardfnc``, ``penalty_array[c]`` and ``active_learning.get_samples()`` unchanged.  All
+numerics run in libdrlvae.so on the GPU; what stays in Python here is what is Python glue in the
+reference too (array assembly, reward constants, argsort).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .formats.keras_h5 import load_keras_vae
+from .formats.tf_bundle import load_q_estimator, load_vae_dense_chain
+from .scorer import WindowScorer
+
+# ------------------------------------------------------------------------------------------ a-1
+
+
+def minmax_params(x, dtype=np.float32):
+    """``MinMaxScaler().fit`` parameters (scale_, min_) as sklearn computes them in ``dtype``
+    (reference env.py:75-79 casts to float32 first; env_smd.py:76-77 fits in float64)."""
+    x = np.asarray(x, dtype=dtype)
+    mn, mx = x.min(), x.max()
+    rng = dtype(mx - mn)
+    if rng == 0 or rng < 10 * np.finfo(dtype).eps:
+        rng = dtype(1.0)
+    scale = dtype(1.0) / rng
+    return scale, dtype(0.0) - mn * scale
+
+
+# ------------------------------------------------------------------------------------------ weights
+
+
+def vae_from_dense_chain(chain, logvar_clip: float = 10.0) -> Dict:
+    """[(kernel, bias), ...] in creation order hidden..., mu, logvar, decoder hidden, output
+    (reference myasp-A1.py:89-99) -> the dict WindowScorer.set_vae takes."""
+    n = len(chain)
+    if n < 4:
+        raise ValueError("a VAE Dense chain has at least mu, logvar, decoder hidden, output")
+    mu = n - 4
+    return {"kernels": [k for k, _ in chain], "biases": [b for _, b in chain],
+            "acts": [1] * mu + [0, 0, 1, 2], "mu_layer": mu, "logvar_layer": mu + 1,
+            "logvar_clip": logvar_clip}
+
+
+_default_scorer: Optional[WindowScorer] = None
+
+
+def default_scorer(device: int = 0) -> WindowScorer:
+    global _default_scorer
+    if _default_scorer is None:
+        _default_scorer = WindowScorer(device)
+    return _default_scorer
+
+
+class KerasVAE:
+    """Stands in for the Keras model returned by ``load_model('vae_model.h5', ...)``
+    (reference myasp-A1.py:567): ``predict(x)`` -> reconstruction, float32 (B, D).
+
+    The reference's ``predict`` samples z = mu + exp(logvar/2)*eps with fresh noise on every call
+    (myasp-A1.py:78-84); this one takes the mean path z = mu unless ``eps`` is given.
+    """
+
+    def __init__(self, vae: Dict, scorer: Optional[WindowScorer] = None):
+        self.config = vae
+        self.scorer = scorer or default_scorer()
+        self.scorer.set_vae(vae)
+        self.input_dim = vae["kernels"][0].shape[0]
+
+    def _bind(self):
+        # several models may share one scorer: re-send the weights when another model was bound
+        if getattr(self.scorer, "_bound_vae", None) is not self:
+            self.scorer.set_vae(self.config)
+            self.scorer._bound_vae = self
+
+    def predict(self, x, batch_size=None, verbose=0, eps=None):
+        self._bind()
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim == 1:
+            x = x[None, :]
+        return self.scorer.vae_predict(x, eps=eps)
+
+    def reconstruction_error(self, x) -> np.ndarray:
+        self._bind()
+        x = np.asarray(x, dtype=np.float32)
+        if x.ndim == 1:
+            x = x[None, :]
+        return self.scorer.vae_predict(x, return_err=True)[1]
+
+
+def load_model(path: str, custom_objects=None, compile: bool = False,
+               scorer: Optional[WindowScorer] = None) -> KerasVAE:
+    """Signature of ``tensorflow.keras.models.load_model`` as the reference calls it
+    (myasp-A1.py:567); ``custom_objects``/``compile`` are accepted and ignored."""
+    return KerasVAE(load_keras_vae(path), scorer)
+
+
+class QEstimator:
+    """Stands in for ``Q_Estimator_Nonlinear`` / ``QNet`` at inference time
+    (reference myasp-A1.py:165-199, myasp-wadi.py:208-229)."""
+
+    def __init__(self, lstm: Dict, scope: str = "qlearn", scorer: Optional[WindowScorer] = None):
+        self.scope = scope
+        self.weights = lstm
+        self.scorer = scorer or default_scorer()
+        self.scorer.set_lstm(lstm)
+        self.scorer._bound_lstm = self
+
+    @classmethod
+    def from_checkpoint(cls, prefix: str, scope: str = "qlearn", scorer=None) -> "QEstimator":
+        return cls(load_q_estimator(prefix, scope), scope, scorer)
+
+    def _bind(self):
+        if getattr(self.scorer, "_bound_lstm", None) is not self:
+            self.scorer.set_lstm(self.weights)
+            self.scorer._bound_lstm = self
+
+    def predict(self, state, sess=None):
+        """``sess.run(self.action_values, {self.state: state})``: state (B, W, I) -> (B, A)."""
+        self._bind()
+        s = np.asarray(state, dtype=np.float32)
+        if s.ndim == 2:
+            s = s[None]
+        return self.scorer.q_predict(s)
+
+
+def vae_from_checkpoint(prefix: str, scorer=None) -> Optional[KerasVAE]:
+    """The VAE Dense layers that ride along in a Saver bundle."""
+    chain = load_vae_dense_chain(prefix)
+    return None if chain is None else KerasVAE(vae_from_dense_chain(chain), scorer)
+
+
+# ------------------------------------------------------------------------------------------ a-2
+
+
+def make_state_fn(n_steps: int = 25):
+    """``RNNBinaryStateFuc`` (reference myasp-A1.py:120-134): the env's pluggable state function.
+    Pure array assembly, kept on the host exactly as in the reference (env.py:92, 143, 162-164
+    call it one cursor at a time); the batched equivalent is the flag modes of the GPU path."""
+
+    def RNNBinaryStateFuc(timeseries, timeseries_curser, previous_state=[], action=None):
+        v = timeseries["value"]
+        if timeseries_curser == n_steps:
+            st = np.zeros((n_steps, 2), dtype="float32")
+            st[:, 0] = np.asarray(v[1:n_steps + 1], dtype="float32")
+            st[-1, 1] = 1
+            return st
+        if timeseries_curser > n_steps:
+            prev = np.asarray(previous_state, dtype="float32")
+            out = np.empty((2, n_steps, 2), dtype="float32")
+            out[:, :n_steps - 1] = prev[1:n_steps]
+            out[:, n_steps - 1, 0] = v[timeseries_curser]
+            out[0, n_steps - 1, 1] = 0
+            out[1, n_steps - 1, 1] = 1
+            return out
+        return None
+
+    return RNNBinaryStateFuc
+
+
+# ------------------------------------------------------------------------------------------ a-5..a-7
+
+
+class RewardFunction:
+    """``RNNBinaryRewardFuc`` (reference myasp-A1.py:137-151; SMD variant myasp-smd.py:136-153).
+
+    The reference calls ``vae.predict`` on one window per ``env.step``.  Here the reconstruction
+    error of *every* window of a series is computed by one fused GPU call the first time the
+    series is seen and then indexed by cursor — same values, one launch per series instead of one
+    Keras dispatch per step.
+    """
+
+    def __init__(self, vae: KerasVAE, n_steps: int = 25, tn=1.0, tp=5.0, fp=-1.0, fn=-5.0,
+                 include_vae_penalty: bool = True, label_column: str = "label"):
+        self.vae, self.W = vae, n_steps
+        self.tn, self.tp, self.fp, self.fn = tn, tp, fp, fn
+        self.include = include_vae_penalty
+        self.label_column = label_column
+        self._cache: Dict[int, np.ndarray] = {}
+
+    def errors_for(self, timeseries) -> np.ndarray:
+        key = id(timeseries)
+        if key not in self._cache:
+            v = np.asarray(timeseries["value"], dtype=np.float32)
+            self.vae._bind()
+            self._cache[key] = self.vae.scorer.score(v, self.W, vae_lag=1, want=("err",))["err"]
+        return self._cache[key]
+
+    def __call__(self, timeseries, timeseries_curser, action=0, vae=None, dynamic_coef=1.0):
+        c = timeseries_curser
+        if c < self.W:
+            return [0, 0]
+        pen = dynamic_coef * float(self.errors_for(timeseries)[c - self.W]) if self.include else 0.0
+        lab = timeseries[self.label_column][c]
+        if lab == 0:
+            return [self.tn + pen, self.fp + pen]
+        if lab == 1:
+            return [self.fn + pen, self.tp + pen]
+        return [0, 0]
+
+
+def penalty_array(values, n_steps: int, vae: KerasVAE, center=None, scale=None, clip: float = 10.0):
+    """The module-level ``penalty_array`` of the WaDi driver (reference myasp-wadi.py:130-149):
+    ``values`` (N, F) raw sensors -> float array (N,), zeros for the first n_steps-1 entries, then
+    the reconstruction error of the window ending at each sample (RobustScaler + clip applied on
+    the device)."""
+    x = np.asarray(values, dtype=np.float32)
+    if x.ndim == 1:
+        x = x[:, None]
+    N = x.shape[0]
+    out = np.zeros(N, dtype=np.float64)
+    if N < n_steps:
+        return out
+    vae._bind()
+    # window ending at sample i (i >= W-1) = window index k = i - W of a series with one
+    # leading pad row; score the padded series with lag 0.
+    padded = np.concatenate([x[:1], x], axis=0)
+    err = vae.scorer.score(padded, n_steps, vae_lag=0, want=("err",), vae_center=center,
+                           vae_scale=scale, vae_clip=clip if center is not None else 0.0)["err"]
+    out[n_steps - 1:] = err
+    return out
+
+
+# ------------------------------------------------------------------------------------------ a-10
+
+
+class active_learning:
+    """``active_learning`` of the drivers (reference myasp-A1.py:242-259): same constructor and
+    ``get_samples`` contract, but the margins of all windows come from one GPU call on the env's
+    current series instead of one ``estimator.predict`` per state."""
+
+    def __init__(self, env, N, strategy, estimator: QEstimator, already_selected, n_steps: int = 25):
+        self.env, self.N, self.strategy = env, N, strategy
+        self.estimator, self.already_selected = estimator, already_selected
+        self.W = n_steps
+
+    def distances(self) -> np.ndarray:
+        self.estimator._bind()
+        v = np.asarray(self.env.timeseries["value"], dtype=np.float32)
+        # env.states_list carries the get_states_list flag quirk
+        return self.estimator.scorer.score(v, self.W, flag_mode="quirk", want=("margin",))["margin"]
+
+    def get_samples(self) -> List[int]:
+        d = self.distances()
+        rank_ind = np.argsort(d)
+        n_states = len(self.env.states_list)
+        sel = set(int(i) for i in self.already_selected)
+        return [int(i) for i in rank_ind if i < n_states and int(i) not in sel][: self.N]
+
+    def get_samples_by_score(self, threshold) -> List[int]:
+        d = self.distances()
+        sel = set(int(i) for i in self.already_selected)
+        return [int(i) for i in np.argsort(d) if int(i) not in sel and d[i] < threshold]

@@ -275,3 +275,85 @@ def test_errors_are_reported_not_crashed(scorer, ckpt_a1):
     bad["w_out"] = np.zeros((130, 2), np.float32)
     with pytest.raises(RuntimeError, match="hidden"):
         scorer.set_lstm(bad)
+
+
+# ----------------------------------------------------------------------------------- sharding / shims
+def test_shards_are_bit_identical_to_the_whole(scorer, a1, ckpt_a1):
+    """Multi-GPU correctness by construction: scoring a halo'd slice gives bit-identical windows."""
+    from drlvae.dist import shard_stream
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    v = a1["series"][7]
+    whole = scorer.score(v, W, flag_mode="zeros")
+    for world in (2, 8):
+        parts = {k: [] for k in whole}
+        for r in range(world):
+            s_lo, s_hi, k_lo, k_hi = shard_stream(len(v), W, r, world)
+            out = scorer.score(v[s_lo:s_hi], W, flag_mode="zeros")
+            for k in whole:
+                parts[k].append(out[k])
+        for k in whole:
+            got = np.concatenate(parts[k])
+            assert np.array_equal(got.view(np.uint32), whole[k].view(np.uint32)), (world, k)
+
+
+def test_reference_call_surface_shims(scorer, a1, ckpt_a1):
+    from drlvae import compat
+    lstm, vae = ckpt_a1
+    model = compat.KerasVAE(vae, scorer)
+    est = compat.QEstimator(lstm, "qlearn", scorer)
+    v = a1["series"][2]
+    ts = {"value": v, "label": np.where(np.arange(len(v)) % 7 == 0, 1, np.where(np.arange(len(v)) % 5 == 0, -1, 0)),
+          "anomaly": a1["anomaly"][2]}
+    # vae.predict on one window, the reference's call pattern (myasp-A1.py:139-141)
+    c = 100
+    cur = np.array([v[c - W:c]])
+    rec = model.predict(cur)
+    want = orc.vae_forward(cur, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
+                           dtype=np.float64)
+    np.testing.assert_allclose(rec, want, rtol=RTOL, atol=1e-7)
+    err_oracle = orc.recon_error(orc.vae_windows_univariate(v, W),
+                                 orc.vae_forward(orc.vae_windows_univariate(v, W), vae["kernels"], vae["biases"],
+                                                 vae["acts"], vae["mu_layer"], vae["logvar_layer"], dtype=np.float64),
+                                 np.float64)
+    rf = compat.RewardFunction(model, W)
+    for c in (10, W, 26, 100, 105, len(v) - 1):
+        got = rf(ts, c, 0, dynamic_coef=2.5)
+        if c < W:
+            assert got == [0, 0]
+            continue
+        want_r = orc.reward_pair(err_oracle[c - W], ts["label"][c], 2.5)
+        np.testing.assert_allclose(got, want_r, rtol=RTOL)
+    # estimator.predict(state=[state]) (myasp-A1.py:254) and active_learning.get_samples
+    states = orc.states_list_univariate(v, W)
+    q1 = est.predict(state=[states[5]])
+    assert q1.shape == (1, 2)
+    qo = orc.lstm_q(states, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64)
+    assert_q_close(q1[0], qo[5])
+
+    class Env:
+        timeseries = ts
+        states_list = list(states)
+
+    al = compat.active_learning(Env(), 15, "margin_sampling", est, already_selected=[3, 4])
+    got = al.get_samples()
+    want_rank = orc.al_get_samples(qo, 15, [3, 4])
+    assert len(got) == 15 and 3 not in got and 4 not in got
+    d = orc.al_margin(qo)
+    assert max(d[got]) <= sorted(d[[i for i in range(len(d)) if i not in (3, 4)]])[14] * (1 + 1e-4) + 1e-6
+    assert len(set(got) & set(want_rank)) >= 13
+    # penalty_array of the WaDi driver (myasp-wadi.py:130-149)
+    rng = np.random.default_rng(9)
+    x = rng.random((120, 3), dtype=np.float32)
+    D = W * 3
+    vae3 = synth_vae(rng, [D, 128, 10, 128, D], 1)
+    m3 = compat.KerasVAE(vae3, scorer)
+    wins = orc.vae_windows_multivariate(x, W, None, None, None)
+    center, scale = orc.robust_scaler_fit(wins[rng.choice(len(wins), 40, replace=False)])
+    pen = compat.penalty_array(x, W, m3, center, scale, 10.0)
+    Xs = orc.vae_windows_multivariate(x, W, center, scale, 10.0)
+    rec = orc.vae_forward(Xs, vae3["kernels"], vae3["biases"], vae3["acts"], 1, 2, dtype=np.float64)
+    want_pen = orc.penalty_array(orc.recon_error(Xs, rec, np.float64), W)
+    assert pen.shape == (120,) and np.all(pen[:W - 1] == 0)
+    np.testing.assert_allclose(pen, want_pen, rtol=RTOL)

@@ -1,0 +1,139 @@
+"""CPU-only tests of the host-side logic: the reference-surface shims that need no GPU, the
+sharding plans and the N>1 gather path (gloo, world size 2, the oracle standing in for the GPU
+scorer — it is the checker here, never the product)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from oracle import ref_path as orc
+
+W = 25
+
+
+def test_state_function_matches_reference_states_list(a1):
+    from drlvae.compat import make_state_fn
+    fn = make_state_fn(W)
+    ts = {"value": a1["series"][0]}
+    assert fn(ts, 10) is None
+    states = [fn(ts, W)]
+    for c in range(W + 1, len(ts["value"])):
+        two = fn(ts, c, states[-1])
+        assert two.shape == (2, W, 2) and two.dtype == np.float32
+        assert two[1, -1, 1] == 1 and two[0, -1, 1] == 0
+        states.append(two[0])
+    want = np.load(os.path.join(GOLDEN, "states_list_real_1.npz"))["states"]
+    assert np.array_equal(np.array(states), want)
+
+
+def test_minmax_params_are_sklearns(a1):
+    from drlvae.compat import minmax_params
+    for raw, want in zip(a1["raw3"], a1["series"][:3]):
+        sc, of = minmax_params(raw)
+        assert sc.dtype == np.float32 and of.dtype == np.float32
+        got = raw * sc + of
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    sc, of = minmax_params(np.full(10, 3.0, np.float32))
+    assert sc == 1.0 and of == -3.0
+
+
+def test_vae_from_dense_chain_layout(ckpt_a1):
+    from drlvae.compat import vae_from_dense_chain
+    _, vae = ckpt_a1
+    v = vae_from_dense_chain(list(zip(vae["kernels"], vae["biases"])))
+    assert v["mu_layer"] == 3 and v["logvar_layer"] == 4 and v["acts"] == [1, 1, 1, 0, 0, 1, 2]
+
+
+def test_shard_plans():
+    from drlvae.dist import deal_series, shard_range, shard_stream
+    for n in (0, 1, 7, 1000):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+    # halo: every shard scored as its own series yields exactly its windows
+    N = 500
+    for world in (2, 4):
+        ks = []
+        for r in range(world):
+            s_lo, s_hi, k_lo, k_hi = shard_stream(N, W, r, world)
+            assert s_hi - s_lo - W == k_hi - k_lo and s_lo == k_lo
+            ks += list(range(k_lo, k_hi))
+        assert ks == list(range(N - W))
+    assert shard_stream(20, W, 0, 2) == (0, 0, 0, 0)
+    lens = [1420, 741, 30, 10, 1461, 900]
+    deal = deal_series(lens, W, 2)
+    assert sorted(deal[0] + deal[1]) == list(range(6))
+    loads = [sum(max(0, lens[i] - W) for i in d) for d in deal]
+    assert abs(loads[0] - loads[1]) <= max(lens)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-reward-rl-vae_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from conftest import load_model_npz
+    from drlvae.dist import score_stream_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lstm, vae = load_model_npz("ckpt_a1.npz")
+    v = np.load(os.path.join(GOLDEN, "a1_series.npz"))["values"][:300]
+
+    def score_fn(x, W, vae_lag=1, flag_mode="zeros", flags=None, want=None, **kw):
+        # the oracle stands in for WindowScorer.score (no GPU in this test)
+        return orc.score_series_univariate(x[:, 0] if x.ndim == 2 else x, W, vae, lstm, flag_mode, actions=None) \
+            if flag_mode != "explicit" else _explicit(x, W, flags)
+
+    def _explicit(x, W, flags):
+        S = orc.states_list_univariate(x, W)
+        idx = np.arange(len(x) - W)[:, None] + 1 + np.arange(W)[None, :]
+        S[:, :, 1] = flags[idx]
+        qv = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"])
+        X = orc.vae_windows_univariate(x, W)
+        rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"])
+        return {"err": orc.recon_error(X, rec), "q": qv, "action": orc.greedy_action(qv), "margin": orc.al_margin(qv)}
+
+    out = {}
+    for mode in ("zeros", "quirk"):
+        out[mode] = score_stream_sharded(score_fn, v, W, flag_mode=mode)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_sharded_scoring_equals_single_process_gloo_world2(ckpt_a1):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lstm, vae = ckpt_a1
+    v = np.load(os.path.join(GOLDEN, "a1_series.npz"))["values"][:300]
+    for mode in ("zeros", "quirk"):
+        want = orc.score_series_univariate(v, W, vae, lstm, mode)
+        for rank in (0, 1):
+            got = results[rank][mode]
+            assert got["err"].shape == (275,)
+            # sharding must not change per-window results (the numpy stand-in's BLAS rounding
+            # depends on the batch shape, hence a tolerance here; the GPU path is asserted
+            # bit-identical under sharding in tests/test_gpu_parity.py)
+            for k in ("err", "q", "margin"):
+                np.testing.assert_allclose(got[k], want[k], rtol=2e-6, atol=1e-6, err_msg=f"{mode}/{k}/rank{rank}")
+            np.testing.assert_array_equal(got["action"], want["action"])
