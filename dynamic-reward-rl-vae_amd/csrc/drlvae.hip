@@ -37,7 +37,7 @@ struct LstmHost {
     bool set = false;
     int I = 0, H = 0, A = 0, NT = 0;
     float forget_bias = 1.0f;
-    size_t wx_off = 0, u_off = 0, bias_off = 0, wout_off = 0, bout_off = 0;
+    size_t wx_off = 0, u_off = 0, bias_off = 0, wout_off = 0, bout_off = 0, flagw_off = 0;
 };
 
 struct Prof {
@@ -61,11 +61,15 @@ struct drl_ctx {
     DevBuf vae_w, lstm_w;       // packed weights
     DevBuf seg;                 // segment tables
     DevBuf opt;                 // per-series / per-column option arrays
+    DevBuf pbuf;                // per-sample input projections of the H<=64 LSTM path
+    bool rec_attr_set = false;
     DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
     void* pinned = nullptr;     // pinned host staging for the segment tables
     size_t pinned_cap = 0;
     Prof prof;
     const char* last_variant = "none";
+    const char* last_vae_variant = "none";
+    size_t wide_lds_set = 0;
     // the segment tables of the last call stay valid on the device while the same series layout is scored again
     std::vector<int64_t> seg_key;
     long long seg_K = 0;
@@ -115,25 +119,28 @@ inline size_t up16(size_t n) { return (n + 15) & ~size_t(15); }
 
 // Dense layer K [din,dout] -> A fragments [out_tile][in_tile][16][64]:
 // lane l of k-step r holds K[in = it*32 + rowmap(r, l>>5)][out = ot*32 + (l&31)] (0 outside).
-void pack_dense(const float* K, int din, int dout, float* dst) {
+// in_major = false: [out_tile][in_tile][16][64] (one OUTPUT tile's weights contiguous: last layer);
+// in_major = true:  [in_tile][out_tile][16][64] (one INPUT tile's weights contiguous: first layer).
+void pack_dense(const float* K, int din, int dout, float* dst, bool in_major, double scale) {
     const int nin = (din + 31) / 32, nout = (dout + 31) / 32;
     for (int ot = 0; ot < nout; ++ot)
         for (int it = 0; it < nin; ++it)
             for (int r = 0; r < 16; ++r)
                 for (int l = 0; l < 64; ++l) {
                     const int in = it * 32 + rowmap_h(r, l >> 5), out = ot * 32 + (l & 31);
-                    dst[(((size_t)ot * nin + it) * 16 + r) * 64 + l] =
-                        (in < din && out < dout) ? K[(size_t)in * dout + out] : 0.0f;
+                    const size_t blk = in_major ? (size_t)it * nout + ot : (size_t)ot * nin + it;
+                    dst[(blk * 16 + r) * 64 + l] =
+                        (in < din && out < dout) ? (float)(scale * K[(size_t)in * dout + out]) : 0.0f;
                 }
 }
 // bias [dout] -> [out_tile][2][16]: entry (ot, half, r) = bias[ot*32 + rowmap(r, half)]
-void pack_bias(const float* b, int dout, float* dst) {
+void pack_bias(const float* b, int dout, float* dst, double scale) {
     const int nout = (dout + 31) / 32;
     for (int ot = 0; ot < nout; ++ot)
         for (int half = 0; half < 2; ++half)
             for (int r = 0; r < 16; ++r) {
                 const int o = ot * 32 + rowmap_h(r, half);
-                dst[(ot * 2 + half) * 16 + r] = o < dout ? b[o] : 0.0f;
+                dst[(ot * 2 + half) * 16 + r] = o < dout ? (float)(scale * b[o]) : 0.0f;
             }
 }
 
@@ -306,7 +313,7 @@ void drl_destroy(drl_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->prof.pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->st_in, &c->st_flags, &c->st_eps,
+    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->pbuf, &c->st_in, &c->st_flags, &c->st_eps,
                       &c->st_err, &c->st_q, &c->st_act, &c->st_margin})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -383,12 +390,15 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
     std::vector<float> pack(off, 0.0f);
     for (int p = 0; p < v.n_path; ++p) {
         const int l = path[p];
-        pack_dense(kernels[l], v.din[p], v.dout[p], pack.data() + v.w_off[p]);
-        pack_bias(biases[l], v.dout[p], pack.data() + v.b_off[p]);
+        // the output sigmoid becomes 1/(1+2^y): fold -log2(e) into the last layer (act code 3)
+        double scale = 1.0;
+        if (p == v.n_path - 1 && v.act[p] == DRL_ACT_SIGMOID) { scale = -1.4426950408889634; v.act[p] = 3; }
+        pack_dense(kernels[l], v.din[p], v.dout[p], pack.data() + v.w_off[p], p == 0, scale);
+        pack_bias(biases[l], v.dout[p], pack.data() + v.b_off[p], scale);
     }
     if (v.has_lv) {
-        pack_dense(kernels[logvar_layer], in_dims[logvar_layer], v.latent, pack.data() + v.wlv_off);
-        pack_bias(biases[logvar_layer], v.latent, pack.data() + v.blv_off);
+        pack_dense(kernels[logvar_layer], in_dims[logvar_layer], v.latent, pack.data() + v.wlv_off, false, 1.0);
+        pack_bias(biases[logvar_layer], v.latent, pack.data() + v.blv_off, 1.0);
     }
     int rc = ensure(c, c->vae_w, off * sizeof(float));
     if (rc) return rc;
@@ -418,6 +428,7 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
     l.bias_off = off; off += (size_t)NT * 32;
     l.wout_off = off; off += up16((size_t)NT * 8 * n_actions);
     l.bout_off = off; off += 16;
+    l.flagw_off = off; off += (size_t)NT * 32;
     std::vector<float> pack(off, 0.0f);
     // gate-interleaved rows: row i of tile tau = (unit 8*tau + (i>>2), gate i&3) -> TF column gate*H + unit
     auto col = [&](int tau, int i) -> int {
@@ -452,6 +463,14 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
                 pack[l.bias_off + (tau * 2 + half) * 16 + r] =
                     cc >= 0 ? (float)(gscale(i) * ((double)bias[cc] + fbias)) : 0.0f;
             }
+    // the flag row of Wx (last input feature) in accumulator order, for the x-projection path
+    for (int tau = 0; tau < NT; ++tau)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r) {
+                const int i = rowmap_h(r, half), cc = col(tau, i);
+                pack[l.flagw_off + (tau * 2 + half) * 16 + r] =
+                    cc >= 0 ? (float)(gscale(i) * kernel[(size_t)(in_dim - 1) * ld + cc]) : 0.0f;
+            }
     for (int u = 0; u < H; ++u)
         for (int a = 0; a < n_actions; ++a) pack[l.wout_off + (size_t)u * n_actions + a] = w_out[(size_t)u * n_actions + a];
     for (int a = 0; a < n_actions; ++a) pack[l.bout_off + a] = b_out[a];
@@ -474,13 +493,14 @@ struct OptDev {
     const float* in_offset = nullptr;
     const float* center = nullptr;
     const float* scale = nullptr;
+    const float* inv_scale = nullptr;
 };
 
 // Uploads the small host-side option arrays (per series / per flattened column).
 int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d) {
     size_t n = 0;
     if (o->in_scale) n += 2 * up16(n_seg);
-    if (o->vae_center) n += 2 * up16(D);
+    if (o->vae_center) n += 3 * up16(D);
     if (!n) return DRL_OK;
     int rc = ensure(c, c->opt, n * sizeof(float));
     if (rc) return rc;
@@ -500,6 +520,10 @@ int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d
         d.center = base + off; off += up16(D);
         HIP_TRY(c, hipMemcpyAsync(base + off, o->vae_scale, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
         d.scale = base + off; off += up16(D);
+        std::vector<float> inv(D);
+        for (int i = 0; i < D; ++i) inv[i] = (float)(1.0 / (double)o->vae_scale[i]);
+        HIP_TRY(c, hipMemcpy(base + off, inv.data(), D * sizeof(float), hipMemcpyHostToDevice));
+        d.inv_scale = base + off; off += up16(D);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DRL_OK;
@@ -554,10 +578,31 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         memset(&a, 0, sizeof a);
         fill_vae_args(c, a);
         a.x = d_series; a.win_stride = F; a.lag_elems = (1 - o->vae_lag) * F; a.D = W * F;
-        a.center = od.center; a.scale = od.scale; a.clip = o->vae_clip;
+        a.center = od.center; a.scale = od.scale; a.inv_scale = od.inv_scale; a.clip = o->vae_clip;
         a.eps = d_eps; a.seg = seg; a.n_tiles = sh.tiles32; a.err = d_err; a.recon = nullptr;
+        // wide windows: stream the first/last layer through LDS when the windows' flat region fits
+        const int xr_floats = (31 * F + ((W * F + 31) & ~31) + 3) & ~3;
+        const size_t wide_lds = ((size_t)2 * VW_WT + 256 + (size_t)4 * xr_floats) * sizeof(float);
+        const bool wide = W * F > 128 && !d_eps && wide_lds <= 160 * 1024 &&
+                          c->vae.dout[0] > 96 && c->vae.dout[0] <= 128 &&
+                          c->vae.din[c->vae.n_path - 1] > 96 && c->vae.din[c->vae.n_path - 1] <= 128;
         prof_begin(c, 1);
-        hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+        if (wide) {
+            if (wide_lds > c->wide_lds_set) {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                c->wide_lds_set = 160 * 1024;
+            }
+            const dim3 grid((sh.tiles32 + 3) / 4);
+            if (a.center) hipLaunchKernelGGL(vae_wide_kernel<true>, grid, dim3(256), wide_lds, c->stream, a, xr_floats);
+            else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, c->stream, a, xr_floats);
+            c->last_vae_variant = "wide";
+        } else {
+            hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+            c->last_vae_variant = "chain";
+        }
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
     }
@@ -575,6 +620,27 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
+        } else if (c->lstm.NT == 8 && !od.in_scale) {
+            // H <= 64: project every sample once, then run the recurrences from the projections
+            const long long n_samples = seg_offsets[n_seg];
+            const size_t pbytes = (size_t)n_samples * 8 * 32 * sizeof(float);
+            if ((rc = ensure(c, c->pbuf, pbytes))) return rc;
+            const size_t lds = (size_t)32 * 8 * 64 * sizeof(float);
+            if (!c->rec_attr_set) {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                c->rec_attr_set = true;
+            }
+            XprojArgs xa;
+            xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
+            xa.P = (float*)c->pbuf.p;
+            hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
+            RecArgs ra;
+            a.n_tiles = sh.tiles32;
+            ra.l = a; ra.P = xa.P; ra.n_samples = n_samples;
+            ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
+            hipLaunchKernelGGL(lstm_rec_kernel<8>, dim3((sh.tiles32 + 3) / 4, a.S), dim3(256), lds, c->stream, ra);
+            c->last_variant = "xproj+rec";
         } else {
             a.n_tiles = sh.tiles32;
             const dim3 grid((sh.tiles32 + 3) / 4, a.S);

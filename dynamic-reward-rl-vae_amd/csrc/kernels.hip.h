@@ -96,6 +96,7 @@ struct VaeArgs {
     int D;                                   // window length in elements (W*F)
     const float* center;                     // [D] or null (RobustScaler)
     const float* scale;                      // [D]
+    const float* inv_scale;                  // [D] 1/scale (wide kernel)
     float clip;                              // <= 0: none
     const float* eps;                        // [K_total, latent] or null
     SegTab seg;
@@ -105,9 +106,11 @@ struct VaeArgs {
     float* recon;                            // [K_total, D] or null (drl_vae_predict)
 };
 
+// act 3 = sigmoid whose layer was packed pre-scaled by -log2(e): 1/(1+2^y)
 __device__ __forceinline__ float apply_act(float y, int act) {
     if (act == 1) return fmaxf(y, 0.0f);
     if (act == 2) return fast_sigmoid(y);
+    if (act == 3) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
     return y;
 }
 
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
 #pragma unroll
                 for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
                     if (ot < nout)
-                        cur[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], bv, cur[ot]);
+                        cur[ot] = mfma32(w[(((size_t)it * nout + ot) * 16 + r) * 64 + lane], bv, cur[ot]);
             }
         }
 #pragma unroll
@@ -250,6 +253,201 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
         }
         sq += __shfl_xor(sq, 32);                      // the two halves hold different rows
         if (a.err && half == 0 && j < count) a.err[wout] = sq / (float)a.D;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K2, wide windows (D = W*F in the hundreds or thousands: SMD 950, WaDi 3075).  The first and the
+// last Dense layer are real GEMMs here ([windows, D] x [D, 128] and back), so their weights are
+// streamed tile by tile (16 KiB = one 32-feature slab x 128 hidden, contiguous in the packed
+// layout) through a double-buffered LDS ring shared by the workgroup's four waves, and each
+// wave's windows are staged ONCE into LDS as the contiguous flat region they overlap in
+// (32 windows of D elements at stride F = (31*F + D) floats), with coalesced loads.  B fragments
+// are then LDS reads at lane stride F (conflict-free for odd F), RobustScaler/clip applied on the
+// fly.  The narrow middle layers chain in registers as in vae_kernel.
+#define VW_WT 4096     // floats per staged weight tile
+__device__ __forceinline__ void vw_stage_load(f32x4 (&reg)[4], const float* __restrict__ src) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(src) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reg[i] = p[i * 256];
+}
+__device__ __forceinline__ void vw_stage_store(const f32x4 (&reg)[4], float* dst) {
+    f32x4* p = reinterpret_cast<f32x4*>(dst) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i * 256] = reg[i];
+}
+// side tile: center[32] | inv_scale[32] | packed bias[32] of feature tile `ft`
+__device__ __forceinline__ float vw_side_load(const VaeArgs& a, const float* __restrict__ bias_p, int ft) {
+    const int t = threadIdx.x;
+    if (t < 32) { const int d = ft * 32 + t; return (a.center && d < a.D) ? a.center[d] : 0.0f; }
+    if (t < 64) { const int d = ft * 32 + t - 32; return (a.center && d < a.D) ? a.inv_scale[d] : 1.0f; }
+    if (t < 96) return bias_p ? bias_p[ft * 32 + t - 64] : 0.0f;
+    return 0.0f;
+}
+
+// Hidden width is fixed at 4 tiles (97..128, zero padded) so that the 64 MFMAs of a weight tile
+// are straight-line code; SCALED selects the RobustScaler/clip transform at compile time.
+template <bool SCALED>
+__global__ __launch_bounds__(256, 1) void vae_wide_kernel(VaeArgs a, int xr_floats) {
+    extern __shared__ __attribute__((aligned(16))) float vw_smem[];
+    float* wt = vw_smem;                         // [2][VW_WT]
+    float* side = vw_smem + 2 * VW_WT;           // [2][128]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    float* xr = vw_smem + 2 * VW_WT + 256 + (size_t)wave * xr_floats;
+    const int tile = blockIdx.x * 4 + wave;
+    const bool active = tile < a.n_tiles;        // wave-uniform; idle waves still stage and sync
+    const float clip = a.clip > 0.0f ? a.clip : 3.0e38f;
+    const int D = a.D;
+
+    int count = 0, jj = 0;
+    long long wout = 0;
+    if (active) {
+        const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
+        const long long samp0 = a.seg.samp_off[s];
+        const long long nsamp = a.seg.samp_off[s + 1] - samp0;
+        const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
+        const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 32;
+        count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
+        jj = j < count ? j : count - 1;
+        wout = a.seg.win_off[s] + k0 + jj;
+        const bool has_norm = a.seg.in_scale != nullptr;
+        const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+        const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+        // flat region of this wave's windows, clamped to the series, zero beyond it (the padded
+        // feature tail of the last tile is read, against zero weights, so it must be finite)
+        const long long e0 = samp0 * a.win_stride + a.lag_elems + k0 * a.win_stride;
+        const long long e_end = (samp0 + nsamp) * a.win_stride;
+        const int len = (int)((count - 1) * a.win_stride + D);
+        const float* __restrict__ src = a.x + e0;
+        for (int i = lane; i < xr_floats; i += 64) {
+            float v = (i < len && e0 + i < e_end) ? src[i] : 0.0f;
+            if (has_norm) v = minmax_apply(v, sc, of);
+            xr[i] = v;
+        }
+    }
+    const float* xw = xr + (size_t)jj * a.win_stride;     // this lane's window inside the region
+
+    f32x16 cur[4], nxt[4];
+    f32x4 stg[4];
+
+    // ---- layer 0: D -> hidden, weights streamed per 32-feature input tile
+    {
+        const int nin = (a.din[0] + 31) >> 5;
+        const float* __restrict__ w = a.w[0];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) cur[ot] = load_bias16(a.b[0], ot, half);
+        vw_stage_load(stg, w);
+        vw_stage_store(stg, wt);
+        if (threadIdx.x < 128) side[threadIdx.x] = vw_side_load(a, nullptr, 0);
+        __syncthreads();
+        for (int it = 0; it < nin; ++it) {
+            const int cb = it & 1;
+            const bool more = it + 1 < nin;
+            float side_next = 0.0f;
+            if (more) {
+                vw_stage_load(stg, w + (size_t)(it + 1) * VW_WT);
+                if (threadIdx.x < 128) side_next = vw_side_load(a, nullptr, it + 1);
+            }
+            if (active) {
+                const float* __restrict__ wb = wt + cb * VW_WT + lane;
+                const float* __restrict__ sb = side + cb * 128;
+                const float* __restrict__ xt = xw + it * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dl = rowmap(r, half);
+                    float bv = xt[dl];
+                    if (SCALED) bv = fminf(fmaxf((bv - sb[dl]) * sb[32 + dl], -clip), clip);
+#pragma unroll
+                    for (int ot = 0; ot < 4; ++ot) cur[ot] = mfma32(wb[(ot * 16 + r) * 64], bv, cur[ot]);
+                }
+            }
+            if (more) {
+                vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
+                if (threadIdx.x < 128) side[(cb ^ 1) * 128 + threadIdx.x] = side_next;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(cur[ot][r], a.act[0]);
+    }
+
+    // ---- middle layers: registers -> registers, small weights straight from L2
+    for (int p = 1; p < a.n - 1; ++p) {
+        const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
+        const float* __restrict__ w = a.w[p];
+        if (active) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+                nxt[ot] = ot < nout ? load_bias16(a.b[p], ot, half) : f32x16{};
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                if (it < nin) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                        for (int ot = 0; ot < 4; ++ot)
+                            if (ot < nout)
+                                nxt[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], nxt[ot]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(nxt[ot][r], a.act[p]);
+        }
+    }
+
+    // ---- last layer: hidden -> D, weights streamed per 32-feature output tile, error fused
+    {
+        const int p = a.n - 1;
+        const int nout = (a.dout[p] + 31) >> 5;
+        const float* __restrict__ w = a.w[p];
+        const int act = a.act[p];
+        float sq = 0.0f;
+        vw_stage_load(stg, w);
+        vw_stage_store(stg, wt);
+        if (threadIdx.x < 128) side[threadIdx.x] = vw_side_load(a, a.b[p], 0);
+        __syncthreads();
+        for (int ot = 0; ot < nout; ++ot) {
+            const int cb = ot & 1;
+            const bool more = ot + 1 < nout;
+            float side_next = 0.0f;
+            if (more) {
+                vw_stage_load(stg, w + (size_t)(ot + 1) * VW_WT);
+                if (threadIdx.x < 128) side_next = vw_side_load(a, a.b[p], ot + 1);
+            }
+            if (active) {
+                const float* __restrict__ wb = wt + cb * VW_WT + lane;
+                const float* __restrict__ sb = side + cb * 128;
+                const float* __restrict__ xt = xw + ot * 32;
+                f32x16 acc = load_bias16(sb + 64, 0, half);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc = mfma32(wb[(it * 16 + r) * 64], cur[it][r], acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dl = rowmap(r, half);
+                    const float y = apply_act(acc[r], act);
+                    float xv = xt[dl];
+                    if (SCALED) xv = fminf(fmaxf((xv - sb[dl]) * sb[32 + dl], -clip), clip);
+                    const float df = (ot * 32 + dl < D) ? y - xv : 0.0f;
+                    sq = fmaf(df, df, sq);
+                }
+            }
+            if (more) {
+                vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
+                if (threadIdx.x < 128) side[(cb ^ 1) * 128 + threadIdx.x] = side_next;
+            }
+            __syncthreads();
+        }
+        sq += __shfl_xor(sq, 32);
+        if (active && a.err && half == 0 && j < count) a.err[wout] = sq / (float)D;
     }
 }
 
@@ -380,6 +578,168 @@ __global__ __launch_bounds__(256, 1) void lstm_generic_kernel(LstmArgs a) {
             const int unit = 8 * (kk >> 2) + 2 * (kk & 3) + half;
             if (unit < a.H) part = fmaf(hw[kk * 64], a.w_out[unit * a.A + act], part);
         }
+        part += __shfl_xor(part, 32);
+        if (half == 0 && j < count)
+            a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = part + a.b_out[act];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multivariate path for H <= 64 (WaDi QNet / SMD): the input projection of a sample,
+// x_n . Wx + b, is the same in every window that contains the sample (W of them) and for both
+// candidate states, so it is computed ONCE per sample (xproj_kernel) instead of W*S times, and
+// the recurrence (lstm_rec_kernel) starts every step from it.
+//
+// P layout: [chunk = (tile*2 + half)*4 + rg][sample][4 floats] where the 4 floats are accumulator
+// registers 4rg..4rg+3 of (tile, half) — i.e. the four gates i,j,f,o of one hidden unit.  Both the
+// producer's stores and the consumer's loads are then 512 contiguous bytes per half-wave.
+struct XprojArgs {
+    const float* x;          // [n_samples, F]
+    long long n_samples;
+    int F;
+    const float* wx;         // packed [ceil(I/2)][NT][64] (the flag row, feature F, is skipped here)
+    const float* bias;       // packed [NT][2][16]
+    float* P;                // [NT*8][n_samples][4]
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void xproj_kernel(XprojArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    const long long n0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (n0 >= a.n_samples) return;
+    const long long n = n0 + j < a.n_samples ? n0 + j : a.n_samples - 1;
+    const float* __restrict__ xr = a.x + n * a.F;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) acc[tl] = load_bias16(a.bias, tl, half);
+    const int nks = (a.F + 1) >> 1;
+#pragma unroll 2
+    for (int ks = 0; ks < nks; ++ks) {
+        const int feat = 2 * ks + half;
+        const float bv = feat < a.F ? xr[feat] : 0.0f;
+        const float* __restrict__ wp = a.wx + ((size_t)ks * NT) * 64 + lane;
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(wp[tl * 64], bv, acc[tl]);
+    }
+    if (n0 + j < a.n_samples) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                f32x4 v = {acc[tl][4 * rg], acc[tl][4 * rg + 1], acc[tl][4 * rg + 2], acc[tl][4 * rg + 3]};
+                *reinterpret_cast<f32x4*>(a.P + (((size_t)(tl * 2 + half) * 4 + rg) * a.n_samples + (n0 + j)) * 4) = v;
+            }
+    }
+}
+
+struct RecArgs {
+    LstmArgs l;
+    const float* P;          // xproj output
+    long long n_samples;
+    const float* flagw;      // packed [NT][2][16]: the flag row of Wx in accumulator order
+};
+
+// 4 waves per workgroup (one per SIMD, the whole register file), each an independent 32-window x 1-candidate recurrence: U (<= 64 KiB)
+// is shared through LDS as A fragments, h_t feeds step t+1 straight from the registers it was
+// computed into (accumulator order == B-operand order), c never leaves registers, no barriers
+// after the weights are staged.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void lstm_rec_kernel(RecArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64]
+    const LstmArgs& a = ra.l;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.u);
+        f32x4* dst = reinterpret_cast<f32x4*>(rec_u);
+        for (int i = threadIdx.x; i < NT * 4 * NT * 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.n_tiles) return;
+    const int cand = blockIdx.y;
+    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
+    const long long samp0 = a.seg.samp_off[s];
+    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
+    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 32;
+    const int count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
+    const int jj = j < count ? j : count - 1;
+    const long long k = k0 + jj;
+    const long long nrow0 = samp0 + a.row0 + k;            // sample of row 0 of this lane's window
+    const float* __restrict__ ul = rec_u + lane;
+
+    f32x16 acc[NT];
+    float c[NT][4], h[NT][4];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) { c[tl][qd] = 0.0f; h[tl][qd] = 0.0f; }
+
+    for (int t = 0; t < a.W; ++t) {
+        // z = P[sample] (+ flag * wf)
+        const float* __restrict__ pp = ra.P + (size_t)(nrow0 + t) * 4;
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(pp + ((size_t)(tl * 2 + half) * 4 + rg) * ra.n_samples * 4);
+                acc[tl][4 * rg] = v[0]; acc[tl][4 * rg + 1] = v[1]; acc[tl][4 * rg + 2] = v[2]; acc[tl][4 * rg + 3] = v[3];
+            }
+        if (a.flag_mode == 3) {
+            if (cand) {
+#pragma unroll
+                for (int tl = 0; tl < NT; ++tl) acc[tl] += load_bias16(ra.flagw, tl, half);
+            }
+        } else if (a.flag_mode > 0) {
+            const float fl = synth_flag(a.flag_mode, k, t, a.W, cand, a.flags, nrow0 + t);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+                const f32x16 wf = load_bias16(ra.flagw, tl, half);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tl][r] = fmaf(fl, wf[r], acc[tl][r]);
+            }
+        }
+        if (t > 0) {
+            // A fragments one k-step ahead of their MFMAs, and no further (bounded registers)
+            float ua[NT], ub[NT];
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) ua[tl] = ul[tl * 64];
+#pragma unroll
+            for (int kk = 0; kk < NT * 4; kk += 2) {
+#pragma unroll
+                for (int tl = 0; tl < NT; ++tl) ub[tl] = ul[((kk + 1) * NT + tl) * 64];
+#pragma unroll
+                for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(ua[tl], h[kk >> 2][kk & 3], acc[tl]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < NT * 4) {
+#pragma unroll
+                    for (int tl = 0; tl < NT; ++tl) ua[tl] = ul[((kk + 2) * NT + tl) * 64];
+                }
+#pragma unroll
+                for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(ub[tl], h[(kk + 1) >> 2][(kk + 1) & 3], acc[tl]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                h[tl][qd] = lstm_cell(acc[tl][4 * qd], acc[tl][4 * qd + 1], acc[tl][4 * qd + 2],
+                                      acc[tl][4 * qd + 3], 0.0f, c[tl][qd]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    for (int act = 0; act < a.A; ++act) {
+        float part = 0.0f;
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int unit = 8 * tl + 2 * qd + half;
+                part = fmaf(h[tl][qd], unit < a.H ? a.w_out[unit * a.A + act] : 0.0f, part);
+            }
         part += __shfl_xor(part, 32);
         if (half == 0 && j < count)
             a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = part + a.b_out[act];

@@ -235,7 +235,7 @@ def test_multivariate_wadi_formulation(scorer, F, H, N):
     scorer.set_lstm(lstm)
     out = scorer.score(x, W, vae_lag=0, flag_mode="both", action_rule="wadi",
                        vae_center=center, vae_scale=scale, vae_clip=10.0)
-    assert scorer.lstm_variant == "generic"
+    assert scorer.lstm_variant == ("xproj+rec" if H <= 64 else "generic")
     want = orc.score_series_multivariate(x, W, vae, lstm, center, scale, 10.0, dtype=np.float64)
     assert out["q"].shape == (N - W, 2, 2)
     np.testing.assert_allclose(out["err"], want["err"], rtol=RTOL)
