@@ -818,6 +818,69 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     return DRL_OK;
 }
 
+int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets, int n_seg, int W,
+                      const float* in_scale, const float* in_offset,
+                      int32_t* action, float* q, int32_t* passes_out) {
+    if (!c) return DRL_ERR_ARG;
+    if (!series || !seg_offsets || n_seg < 1 || W < 2 || !action)
+        return fail(c, DRL_ERR_ARG, "drl_rollout_batch: bad arguments");
+    if (!c->lstm.set) return fail(c, DRL_ERR_STATE, "drl_rollout_batch: drl_set_lstm was not called");
+    if (c->lstm.I != 2) return fail(c, DRL_ERR_ARG, "drl_rollout_batch: the action feedback exists only for univariate states (in_dim 2)");
+    if (seg_offsets[0] != 0) return fail(c, DRL_ERR_ARG, "seg_offsets[0] must be 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const long long total = seg_offsets[n_seg];
+    const long long K = count_windows(seg_offsets, n_seg, W);
+    if (passes_out) *passes_out = 0;
+    if (K == 0) return DRL_OK;
+    const int A = c->lstm.A;
+    int rc;
+    if ((rc = ensure(c, c->st_in, (size_t)total * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->st_q, (size_t)K * A * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t) + 64))) return rc;
+    if ((rc = ensure(c, c->st_margin, 256))) return rc;             // the "changed" word
+    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    drl_score_opts o;
+    memset(&o, 0, sizeof o);
+    o.struct_size = sizeof o; o.vae_lag = 1; o.flag_mode = DRL_FLAG_EXPLICIT; o.action_rule = DRL_ACTION_ARGMAX;
+    o.flags = (const float*)c->st_flags.p;
+    o.in_scale = in_scale; o.in_offset = in_offset;
+    SegHost sh;
+    if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
+    SegTab seg;
+    memset(&seg, 0, sizeof seg);
+    seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t32; seg.n_seg = n_seg; seg.W = W;
+    float* d_flags = (float*)c->st_flags.p;
+    int* d_changed = (int*)c->st_margin.p;
+    hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_flags, seg, total);
+    hipLaunchKernelGGL(rollout_init1_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, c->stream, d_flags, seg);
+    HIP_TRY(c, hipGetLastError());
+    int passes = 0;
+    long long max_K = 0;
+    for (int i = 0; i < n_seg; ++i) max_K = std::max<long long>(max_K, seg_offsets[i + 1] - seg_offsets[i] - W);
+    for (;;) {
+        rc = score_impl(c, (const float*)c->st_in.p, seg_offsets, n_seg, 1, W, &o, d_flags, nullptr,
+                        nullptr, (float*)c->st_q.p, (int32_t*)c->st_act.p, nullptr, nullptr);
+        if (rc) return rc;
+        ++passes;
+        HIP_TRY(c, hipMemsetAsync(d_changed, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(rollout_feedback_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int*)c->st_act.p, d_flags, seg, K, d_changed);
+        HIP_TRY(c, hipGetLastError());
+        int changed = 0;
+        HIP_TRY(c, hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!changed) break;
+        if (passes > max_K + 1)
+            return fail(c, DRL_ERR_STATE, "drl_rollout_batch: no fixed point after %d passes", passes);
+    }
+    HIP_TRY(c, hipMemcpyAsync(action, c->st_act.p, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (q) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)K * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (passes_out) *passes_out = passes;
+    return DRL_OK;
+}
+
 int drl_profile_enable(drl_ctx* c, int on) {
     if (!c) return DRL_ERR_ARG;
     c->prof.on = on != 0;

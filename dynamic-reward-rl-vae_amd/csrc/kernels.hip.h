@@ -939,3 +939,37 @@ __global__ void finalize_kernel(const float* __restrict__ q, long long K, int S,
     }
     if (margin) margin[k] = fabsf(q0 - q1);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sequential validator rollout (reference myasp-A1.py:481-496 with env.py:126-151) as a
+// fixed-point iteration.  The action at cursor c is fed back as the flag of sample c+1, so a_c
+// depends on a_{c-W+1..c-1}: a true recurrence over actions.  Scoring all windows with a GUESS
+// of the action history and taking the greedy actions gives a' = F(guess); because the
+// dependence is causal, the prefix of a' up to the first wrong guess is already final, so
+// iterating a <- F(a) extends the correct prefix every pass and stops at a = F(a), the exact
+// sequential rollout, after (number of action changes + 1) full-parallel passes.
+//
+// One thread per window: writes flag[sample of cursor k+W+1] = action[k] and reports a change.
+__global__ void rollout_feedback_kernel(const int* __restrict__ action, float* __restrict__ flags,
+                                        SegTab seg, long long K_total, int* __restrict__ changed) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= K_total) return;
+    int lo = 0, hi = seg.n_seg;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg.win_off[mid] <= g) lo = mid; else hi = mid; }
+    const long long k = g - seg.win_off[lo];
+    const long long Ks = seg.win_off[lo + 1] - seg.win_off[lo];
+    if (k + 1 >= Ks) return;                               // the last action feeds no later state
+    const long long n = seg.samp_off[lo] + seg.W + 1 + k;
+    const float nf = (float)action[g];
+    if (flags[n] != nf) { flags[n] = nf; *changed = 1; }
+}
+// initial state: flags 0 except the 1 the first state carries in its last row (myasp-A1.py:126)
+__global__ void rollout_init_kernel(float* __restrict__ flags, SegTab seg, long long n_total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_total) flags[i] = 0.0f;
+}
+__global__ void rollout_init1_kernel(float* __restrict__ flags, SegTab seg) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= seg.n_seg) return;
+    if (seg.samp_off[s + 1] - seg.samp_off[s] > seg.W) flags[seg.samp_off[s] + seg.W] = 1.0f;
+}

@@ -212,6 +212,25 @@ class WindowScorer:
                     "drl_q_predict")
         return q
 
+    def rollout(self, series, W: int, offsets: Optional[Sequence[int]] = None, in_scale=None, in_offset=None,
+                return_q: bool = False):
+        """Greedy validation rollout with action feedback (reference myasp-A1.py:471-496) of one
+        or several univariate series.  Returns actions [K] (and Q [K, A], and the pass count)."""
+        x = _f32(series).reshape(-1)
+        off = np.ascontiguousarray([0, len(x)] if offsets is None else offsets, dtype=np.int64)
+        K = int(self.window_counts(off, W).sum())
+        act = np.empty(K, np.int32)
+        q = np.empty((K, self.n_actions), np.float32) if return_q else None
+        sc = None if in_scale is None else _f32(in_scale)
+        of = None if in_offset is None else _f32(in_offset)
+        passes = C.c_int32(0)
+        rc = self._lib.drl_rollout_batch(self._h, x.ctypes.data, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         len(off) - 1, int(W), _ptr(sc), _ptr(of), act.ctypes.data, _ptr(q),
+                                         C.byref(passes))
+        self._check(rc, "drl_rollout_batch")
+        self.last_rollout_passes = passes.value
+        return (act, q) if return_q else act
+
     # ------------------------------------------------------------------ measurement
     def profile(self, on: bool):
         self._check(self._lib.drl_profile_enable(self._h, 1 if on else 0), "drl_profile_enable")

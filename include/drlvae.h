@@ -154,6 +154,20 @@ int drl_vae_predict(drl_ctx* ctx, const float* x, int64_t B, const float* eps,
  * states [B,W,in_dim] -> q [B,A]. */
 int drl_q_predict(drl_ctx* ctx, const float* states, int64_t B, int W, float* q);
 
+/* ---- sequential validator rollout --------------------------------------------------------------- */
+
+/* Replaces q_learning_validator's inner loop (reference myasp-A1.py:471-496 driving env.reset /
+ * env.step, env.py:82-94, 126-151) for univariate series: start from the initial state (flags
+ * [0]*(W-1)+[1]), act greedily (np.argmax, ties -> 0), feed each action back as the flag of the
+ * next sample.  Computed as a fixed-point iteration over full-parallel teacher-forced passes
+ * (exactly the sequential result; see rollout_feedback_kernel).  Host pointers, synchronous.
+ *   action [K_total] (required), q [K_total, A] (optional) = Q of the state the policy saw at each
+ *   cursor; passes_out (optional) = number of parallel passes it took.
+ * in_scale/in_offset: optional per-series MinMax parameters as in drl_score_opts. */
+int drl_rollout_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg, int W,
+                      const float* in_scale, const float* in_offset,
+                      int32_t* action, float* q, int32_t* passes_out);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* With profiling on, every kernel launch of the scoring path is bracketed by hipEvents on the

@@ -357,3 +357,48 @@ def test_reference_call_surface_shims(scorer, a1, ckpt_a1):
     want_pen = orc.penalty_array(orc.recon_error(Xs, rec, np.float64), W)
     assert pen.shape == (120,) and np.all(pen[:W - 1] == 0)
     np.testing.assert_allclose(pen, want_pen, rtol=RTOL)
+
+
+# ----------------------------------------------------------------------------------- a-3 rollout
+def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckpt_a2):
+    """The sequential validator (action fed back through the flag channel) on the GPU: identical
+    actions to the oracle's literal step-by-step rollout, and through them the reference's own
+    committed exp/*performance.txt numbers (soft known-answer test)."""
+    import json
+    from conftest import split_series
+    kat = json.load(open(os.path.join(GOLDEN, "soft_kat.json")))
+    # A2: all nine committed episodes exactly
+    z = np.load(os.path.join(GOLDEN, "a2_val_series.npz"))
+    series = split_series(z)
+    off = z["offsets"]
+    lstm, _ = ckpt_a2
+    scorer.set_lstm(lstm)
+    acts, q = scorer.rollout(z["values"], W, off, return_q=True)
+    assert scorer.last_rollout_passes < 200
+    pos = 0
+    for i, s in enumerate(series):
+        k = len(s) - W
+        a = acts[pos:pos + k]
+        want = orc.rollout_greedy(s, W, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"])
+        assert np.array_equal(a, want), i
+        p, r, f = orc.precision_recall_f1(z["anomaly"][off[i]:off[i + 1]][W:], a)
+        assert (p, r, f) == pytest.approx(tuple(kat["a2"]["perf"][i]), abs=1e-9)
+        pos += k
+    # A1: same actions as the oracle on the six validation series (4/6 episodes match the file)
+    lstm, _ = ckpt_a1
+    scorer.set_lstm(lstm)
+    exact = 0
+    for jx, want_perf in enumerate(kat["a1"]["perf"]):
+        idx = kat["a1"]["first_index"] + jx
+        s = a1["series"][idx]
+        a = scorer.rollout(s, W)
+        want = orc.rollout_greedy(s, W, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"])
+        assert np.array_equal(a, want), jx
+        prf = orc.precision_recall_f1(a1["anomaly"][idx][W:], a)
+        exact += prf == pytest.approx(tuple(want_perf), abs=1e-9)
+    assert exact >= 4
+    # device-side MinMax in the rollout: raw values + (scale, offset) give the same actions
+    raw = a1["raw3"][0]
+    sc, of = orc.minmax_f32(raw)[1:]
+    a_raw = scorer.rollout(raw, W, in_scale=[sc], in_offset=[of])
+    assert np.array_equal(a_raw, scorer.rollout(a1["series"][0], W))
