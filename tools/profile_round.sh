@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box: bench of every workload, rocprofv3 kernel stats and PMC passes for C2.
+# Results land in gpurun_out/round/ ; copy what matters into profiles/rNN/.
+set -e
+out=gpurun_out/round; mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 300 python -u bench.py > $out/bench_c2.json 2> $out/bench_c2.err
+for w in c1 c3 c4 c5; do
+  timeout -k 10 300 python -u bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --no-cpu-baseline > $out/trace_c2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c4 -- python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c4.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $out/pmc_sq -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_sq.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_inst -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_inst.log 2>&1
+for f in $out/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); r=d["roofline"]
+print(sys.argv[1].split("_")[-1][:2], f"{d['value']/1e6:.2f} Mwin/s", f"lstm {r['avg_launch_ms']:.3f} ms frac {r['frac']:.3f}", f"vae {r['vae_kernel_avg_ms']:.3f} ms", d["config"]["lstm_kernel"], d.get("cpu_baseline",{}).get("value"))
+PY
+done
