@@ -2,6 +2,7 @@
 // Host side: weight re-packing into MFMA fragment order, series segment tables, launches.
 #include "../../include/drlvae.h"
 #include "kernels.hip.h"
+#include "lstm_f16x3.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -38,6 +39,8 @@ struct LstmHost {
     int I = 0, H = 0, A = 0, NT = 0;
     float forget_bias = 1.0f;
     size_t wx_off = 0, u_off = 0, bias_off = 0, wout_off = 0, bout_off = 0, flagw_off = 0;
+    size_t uhi_off = 0, ulo_off = 0;      // f16 hi/lo split of U (H = 128 only), float offsets, 16-B aligned
+    bool has_split = false;
 };
 
 struct Prof {
@@ -63,6 +66,7 @@ struct drl_ctx {
     DevBuf opt;                 // per-series / per-column option arrays
     DevBuf pbuf;                // per-sample input projections of the H<=64 LSTM path
     bool rec_attr_set = false;
+    int lstm_math = 0;          // 0 = exact fp32 MFMA, 1 = 3-term f16 split for the H=128 univariate kernel
     DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
     void* pinned = nullptr;     // pinned host staging for the segment tables
     size_t pinned_cap = 0;
@@ -329,6 +333,13 @@ int drl_set_stream(drl_ctx* c, void* s) {
     return DRL_OK;
 }
 
+int drl_set_lstm_math(drl_ctx* c, int mode) {
+    if (!c) return DRL_ERR_ARG;
+    if (mode != 0 && mode != 1) return fail(c, DRL_ERR_ARG, "drl_set_lstm_math: mode %d (0 = fp32, 1 = f16x3)", mode);
+    c->lstm_math = mode;
+    return DRL_OK;
+}
+
 int drl_synchronize(drl_ctx* c) {
     if (!c) return DRL_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -429,6 +440,12 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
     l.wout_off = off; off += up16((size_t)NT * 8 * n_actions);
     l.bout_off = off; off += 16;
     l.flagw_off = off; off += (size_t)NT * 32;
+    l.has_split = (in_dim == 2 && hidden == 128);
+    if (l.has_split) {
+        off = up16(off);
+        l.uhi_off = off; off += (size_t)16 * 8 * 64 * 4;     // [16 tiles][8 k-steps][64 lanes] x 8 f16 = 4 floats
+        l.ulo_off = off; off += (size_t)16 * 8 * 64 * 4;
+    }
     std::vector<float> pack(off, 0.0f);
     // gate-interleaved rows: row i of tile tau = (unit 8*tau + (i>>2), gate i&3) -> TF column gate*H + unit
     auto col = [&](int tau, int i) -> int {
@@ -463,6 +480,25 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
                 pack[l.bias_off + (tau * 2 + half) * 16 + r] =
                     cc >= 0 ? (float)(gscale(i) * ((double)bias[cc] + fbias)) : 0.0f;
             }
+    if (l.has_split) {
+        // f16 fragments of U for the 3-term split kernel (lstm_f16x3.hip.h): lane (ha, row) of k-step s
+        // holds, at i = 4*half' + q, the weight of hidden unit 8*(2s+ha) + 2q + half' into gate row `row`.
+        _Float16* hi = reinterpret_cast<_Float16*>(pack.data() + l.uhi_off);
+        _Float16* lo = reinterpret_cast<_Float16*>(pack.data() + l.ulo_off);
+        for (int tau = 0; tau < 16; ++tau)
+            for (int s8 = 0; s8 < 8; ++s8)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = ln & 31, ha = ln >> 5;
+                        const int unit = 8 * (2 * s8 + ha) + 2 * (i & 3) + (i >> 2);
+                        const int cc = col(tau, row);
+                        const float wv = (float)(gscale(row) * kernel[(size_t)(in_dim + unit) * ld + cc]);
+                        const _Float16 h16 = (_Float16)wv;
+                        const size_t o = (((size_t)tau * 8 + s8) * 64 + ln) * 8 + i;
+                        hi[o] = h16;
+                        lo[o] = (_Float16)(wv - (float)h16);
+                    }
+    }
     // the flag row of Wx (last input feature) in accumulator order, for the x-projection path
     for (int tau = 0; tau < NT; ++tau)
         for (int half = 0; half < 2; ++half)
@@ -616,7 +652,15 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.q = d_q;
         const bool fast = c->lstm.I == 2 && c->lstm.H == 128 && F == 1 && W >= 2 && W + 65 <= H128_SV;
         prof_begin(c, 0);
-        if (fast) {
+        if (fast && c->lstm_math == 1 && c->lstm.has_split) {
+            a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+            LstmF16Args fa;
+            fa.l = a;
+            fa.uhi = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.uhi_off);
+            fa.ulo = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.ulo_off);
+            hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, fa);
+            c->last_variant = "h128i2_f16x3";
+        } else if (fast) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";

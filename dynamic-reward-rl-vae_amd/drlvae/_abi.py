@@ -15,7 +15,7 @@ ACTION_ARGMAX, ACTION_WADI = 0, 1
 # every symbol include/drlvae.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
-    "drl_set_vae", "drl_set_lstm", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
+    "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
     "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
     "drl_last_lstm_variant",
 ]
@@ -64,6 +64,7 @@ def load():
     lib.drl_version.restype = C.c_char_p
     lib.drl_set_stream.argtypes = [vp, vp]
     lib.drl_synchronize.argtypes = [vp]
+    lib.drl_set_lstm_math.argtypes = [vp, C.c_int]
     lib.drl_set_vae.argtypes = [vp, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int,
                                 C.POINTER(vp), C.POINTER(vp), C.c_float]
     lib.drl_set_lstm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]

@@ -62,6 +62,11 @@ class WindowScorer:
     def set_stream(self, hip_stream: Optional[int]):
         self._check(self._lib.drl_set_stream(self._h, C.c_void_p(hip_stream or 0)), "drl_set_stream")
 
+    def set_lstm_math(self, mode):
+        """"fp32" (exact fp32 MFMA, default) or "f16x3" (3-term compensated f16 split, H=128 univariate)."""
+        m = {"fp32": 0, "f16x3": 1}.get(mode, mode)
+        self._check(self._lib.drl_set_lstm_math(self._h, int(m)), "drl_set_lstm_math")
+
     # ------------------------------------------------------------------ weights
     def set_vae(self, vae: Dict):
         """vae: {"kernels", "biases", "acts", "mu_layer", "logvar_layer", "logvar_clip"} in the

@@ -116,6 +116,14 @@ int drl_set_vae(drl_ctx* ctx, int n_layers, const int32_t* in_dims, const int32_
 int drl_set_lstm(drl_ctx* ctx, int in_dim, int hidden, int n_actions, float forget_bias,
                  const float* kernel, const float* bias, const float* w_out, const float* b_out);
 
+/* Arithmetic of the recurrent product h.U in the univariate H=128 LSTM kernel (no counterpart in
+ * the reference; TensorFlow computes it in fp32):
+ *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default;
+ *   1  3-term error-compensated f16 split (h_hi.U_hi + h_hi.U_lo + h_lo.U_hi with fp32 accumulate)
+ *      on the half-precision matrix pipe: same accuracy class as fp32 (tests hold it to the same
+ *      1e-5 tolerance), ~5x fewer matrix cycles.  Other kernels ignore the setting. */
+int drl_set_lstm_math(drl_ctx* ctx, int mode);
+
 /* ---- the fused path ------------------------------------------------------------------------- */
 
 /* Scores every sliding window of n_seg independent series (windows never cross a series).

@@ -402,3 +402,49 @@ def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckp
     sc, of = orc.minmax_f32(raw)[1:]
     a_raw = scorer.rollout(raw, W, in_scale=[sc], in_offset=[of])
     assert np.array_equal(a_raw, scorer.rollout(a1["series"][0], W))
+
+
+# ----------------------------------------------------------------------------------- f16x3 split
+def test_f16x3_split_kernel_meets_the_fp32_tolerance(scorer, a1, ckpt_a1):
+    """The 3-term compensated f16 split of h.U is held to the same bar as the exact-fp32 kernel."""
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    scorer.set_lstm_math("f16x3")
+    try:
+        exp = np.load(os.path.join(GOLDEN, "c1_expected.npz"))
+        v = a1["series"][0]
+        out = scorer.score(v, W, flag_mode="quirk")
+        assert scorer.lstm_variant == "h128i2_f16x3"
+        assert_q_close(out["q"], exp["q_f64"], "f16x3 q vs fp64 oracle")
+        assert_actions(out["action"], exp["q_f64"], exp["action_f64"])
+        out = scorer.score(v, W, flag_mode="zeros", want=("q",))
+        assert_q_close(out["q"], exp["q_zeros_f64"], "f16x3 zeros")
+        # all 67 series, ragged tiles
+        series = a1["series"]
+        off = np.concatenate([[0], np.cumsum([len(s) for s in series])])
+        out = scorer.score(np.concatenate(series), W, off, flag_mode="quirk", want=("q", "action"))
+        pos = 0
+        worst = 0.0
+        for s in series[:20]:
+            r = orc.score_series_univariate(s, W, vae, lstm, "quirk", dtype=np.float64)
+            k = len(s) - W
+            assert_q_close(out["q"][pos:pos + k], r["q"])
+            worst = max(worst, float(np.max(np.abs(out["q"][pos:pos + k] - r["q"]) / np.abs(r["q"]).max(axis=1, keepdims=True))))
+            pos += k
+        assert worst < 2e-6            # measured ~3e-7: the same class as the exact-fp32 kernel
+        # W = 50 synthetic (C5 shape) and the sequential rollout through this kernel
+        rng = np.random.default_rng(50)
+        vs = rng.random(50 + 333, dtype=np.float32)
+        l2 = synth_lstm(rng, 2, 128)
+        scorer.set_lstm(l2)
+        got = scorer.score(vs, 50, flag_mode="zeros", want=("q",))["q"]
+        S = orc.states_list_univariate(vs, 50)
+        S[:, :, 1] = 0
+        assert_q_close(got, orc.lstm_q(S, l2["kernel"], l2["bias"], l2["w_out"], l2["b_out"], dtype=np.float64))
+        scorer.set_lstm(lstm)
+        s65 = a1["series"][61]
+        assert np.array_equal(scorer.rollout(s65, W),
+                              orc.rollout_greedy(s65, W, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"]))
+    finally:
+        scorer.set_lstm_math("fp32")
