@@ -4,6 +4,8 @@
 #include "kernels.hip.h"
 #include "lstm_f16x3.hip.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -65,6 +67,7 @@ struct drl_ctx {
     DevBuf seg;                 // segment tables
     DevBuf opt;                 // per-series / per-column option arrays
     DevBuf pbuf;                // per-sample input projections of the H<=64 LSTM path
+    DevBuf al_keys, al_keys2, al_idx, al_idx2, al_tmp, al_sel;   // active-learning selection scratch
     bool rec_attr_set = false;
     int lstm_math = 0;          // 0 = exact fp32 MFMA, 1 = 3-term f16 split for the H=128 univariate kernel
     DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
@@ -317,7 +320,7 @@ void drl_destroy(drl_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->prof.pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->pbuf, &c->st_in, &c->st_flags, &c->st_eps,
+    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->pbuf, &c->al_keys, &c->al_keys2, &c->al_idx, &c->al_idx2, &c->al_tmp, &c->al_sel, &c->st_in, &c->st_flags, &c->st_eps,
                       &c->st_err, &c->st_q, &c->st_act, &c->st_margin})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -664,7 +667,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
-        } else if (c->lstm.NT == 8 && !od.in_scale) {
+        } else if (c->lstm.NT == 8 && !od.in_scale &&
+                   (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)16 << 30)) {   // projections: 1 KiB per sample
             // H <= 64: project every sample once, then run the recurrences from the projections
             const long long n_samples = seg_offsets[n_seg];
             const size_t pbytes = (size_t)n_samples * 8 * 32 * sizeof(float);
@@ -922,6 +926,72 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
     if (q) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)K * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (passes_out) *passes_out = passes;
+    return DRL_OK;
+}
+
+int drl_al_get_samples(drl_ctx* c, const float* series, const int64_t* seg_offsets, int n_seg, int F, int W,
+                       const drl_score_opts* o, const int32_t* already_selected, int n_selected, int N,
+                       int32_t* out_idx, int32_t* n_out, float* margin_out) {
+    if (!c) return DRL_ERR_ARG;
+    if (!series || !seg_offsets || n_seg < 1 || F < 1 || W < 1 || !out_idx || !n_out || N < 0 ||
+        n_selected < 0 || (n_selected > 0 && !already_selected))
+        return fail(c, DRL_ERR_ARG, "drl_al_get_samples: bad arguments");
+    int rc = check_opts(c, o, F);
+    if (rc) return rc;
+    *n_out = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (seg_offsets[0] != 0) return fail(c, DRL_ERR_ARG, "seg_offsets[0] must be 0");
+    const long long total = seg_offsets[n_seg];
+    const long long K = count_windows(seg_offsets, n_seg, W);
+    if (K == 0 || N == 0) return DRL_OK;
+    if (K > 0x7fffffffLL) return fail(c, DRL_ERR_ARG, "drl_al_get_samples: more than 2^31 windows");
+    const int S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
+    if ((rc = ensure(c, c->st_in, (size_t)total * F * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->st_q, (size_t)K * S * c->lstm.A * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->st_margin, (size_t)K * sizeof(float)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const float* d_flags = nullptr;
+    if (o->flag_mode == DRL_FLAG_EXPLICIT) {
+        if ((rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->st_flags.p, o->flags, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_flags = (const float*)c->st_flags.p;
+    }
+    rc = score_impl(c, (const float*)c->st_in.p, seg_offsets, n_seg, F, W, o, d_flags, nullptr, nullptr,
+                    (float*)c->st_q.p, nullptr, (float*)c->st_margin.p, nullptr);
+    if (rc) return rc;
+    // keys = margins (already selected -> NaN, which the radix order puts last), values = window index
+    for (DevBuf* b : {&c->al_keys, &c->al_keys2})
+        if ((rc = ensure(c, *b, (size_t)K * sizeof(float)))) return rc;
+    for (DevBuf* b : {&c->al_idx, &c->al_idx2})
+        if ((rc = ensure(c, *b, (size_t)K * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(al_prepare_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float*)c->st_margin.p, K, (float*)c->al_keys.p, (int*)c->al_idx.p);
+    int n_valid_sel = 0;
+    if (n_selected > 0) {
+        std::vector<int32_t> uniq(already_selected, already_selected + n_selected);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        for (int32_t v : uniq) n_valid_sel += (v >= 0 && v < K);
+        if ((rc = ensure(c, c->al_sel, uniq.size() * sizeof(int32_t)))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->al_sel.p, uniq.data(), uniq.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // uniq is a local
+        hipLaunchKernelGGL(al_mask_kernel, dim3((unsigned)((uniq.size() + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int*)c->al_sel.p, (int)uniq.size(), K, (float*)c->al_keys.p);
+    }
+    HIP_TRY(c, hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const float*)c->al_keys.p, (float*)c->al_keys2.p,
+                                                  (const int*)c->al_idx.p, (int*)c->al_idx2.p, (int)K, 0, 32, c->stream));
+    if ((rc = ensure(c, c->al_tmp, tmp_bytes))) return rc;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->al_tmp.p, tmp_bytes, (const float*)c->al_keys.p, (float*)c->al_keys2.p,
+                                                  (const int*)c->al_idx.p, (int*)c->al_idx2.p, (int)K, 0, 32, c->stream));
+    const long long take = std::min<long long>(N, K - n_valid_sel);
+    if (take > 0)
+        HIP_TRY(c, hipMemcpyAsync(out_idx, c->al_idx2.p, (size_t)take * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (margin_out)
+        HIP_TRY(c, hipMemcpyAsync(margin_out, c->st_margin.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_out = (int32_t)std::max<long long>(take, 0);
     return DRL_OK;
 }
 

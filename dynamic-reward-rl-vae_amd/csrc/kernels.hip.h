@@ -973,3 +973,22 @@ __global__ void rollout_init1_kernel(float* __restrict__ flags, SegTab seg) {
     if (s >= seg.n_seg) return;
     if (seg.samp_off[s + 1] - seg.samp_off[s] > seg.W) flags[seg.samp_off[s] + seg.W] = 1.0f;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Active-learning selection (reference myasp-A1.py:250-259): rank windows by margin |q0-q1|,
+// skip the already labelled ones, take the N most confused.  Keys are prepared here; the sort is
+// a stable device radix sort (ties keep ascending window order).
+__global__ void al_prepare_kernel(const float* __restrict__ margin, long long K, float* __restrict__ keys,
+                                  int* __restrict__ idx) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float m = margin[k];
+    keys[k] = (m == m) ? m : __builtin_huge_valf();      // NaN margins rank last, like np.argsort
+    idx[k] = (int)k;
+}
+__global__ void al_mask_kernel(const int* __restrict__ selected, int n_sel, long long K, float* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sel) return;
+    const int k = selected[i];
+    if (k >= 0 && k < K) keys[k] = __builtin_nanf("");    // sorts after +inf in the radix order of floats
+}

@@ -16,7 +16,7 @@ ACTION_ARGMAX, ACTION_WADI = 0, 1
 SYMBOLS = [
     "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
     "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
-    "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
+    "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
     "drl_last_lstm_variant",
 ]
 
@@ -75,6 +75,8 @@ def load():
     lib.drl_vae_predict.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
     lib.drl_q_predict.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
     lib.drl_rollout_batch.argtypes = [vp, vp, _i64p, C.c_int, C.c_int, vp, vp, vp, vp, _i32p]
+    lib.drl_al_get_samples.argtypes = [vp, vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(ScoreOpts), vp, C.c_int,
+                                       C.c_int, vp, _i32p, vp]
     lib.drl_profile_enable.argtypes = [vp, C.c_int]
     lib.drl_profile_reset.argtypes = [vp]
     lib.drl_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), _i64p]

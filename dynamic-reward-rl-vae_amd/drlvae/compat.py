@@ -244,11 +244,10 @@ class active_learning:
         return self.estimator.scorer.score(v, self.W, flag_mode="quirk", want=("margin",))["margin"]
 
     def get_samples(self) -> List[int]:
-        d = self.distances()
-        rank_ind = np.argsort(d)
-        n_states = len(self.env.states_list)
-        sel = set(int(i) for i in self.already_selected)
-        return [int(i) for i in rank_ind if i < n_states and int(i) not in sel][: self.N]
+        self.estimator._bind()
+        v = np.asarray(self.env.timeseries["value"], dtype=np.float32)
+        # scoring, ranking and the already_selected mask all happen on the device
+        return self.estimator.scorer.al_get_samples(v, self.W, self.N, self.already_selected, flag_mode="quirk")
 
     def get_samples_by_score(self, threshold) -> List[int]:
         d = self.distances()

@@ -236,6 +236,29 @@ class WindowScorer:
         self.last_rollout_passes = passes.value
         return (act, q) if return_q else act
 
+    def al_get_samples(self, series, W: int, N: int, already_selected=(), offsets=None, *, flag_mode="quirk",
+                       action_rule="argmax", return_margin: bool = False, **opt):
+        """The N most confused windows (smallest |q0-q1|) not yet in ``already_selected``, ranked on
+        the device (reference myasp-A1.py:250-259)."""
+        x = _f32(series)
+        if x.ndim == 1:
+            x = x[:, None]
+        n, F = x.shape
+        off = np.ascontiguousarray([0, n] if offsets is None else offsets, dtype=np.int64)
+        K = int(self.window_counts(off, W).sum())
+        keep = []
+        o = self._opts(keep, 1, flag_mode, action_rule, **opt)
+        sel = np.ascontiguousarray(list(already_selected), dtype=np.int32)
+        out = np.empty(max(int(N), 1), np.int32)
+        n_out = C.c_int32(0)
+        margin = np.empty(K, np.float32) if return_margin else None
+        rc = self._lib.drl_al_get_samples(self._h, x.ctypes.data, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          len(off) - 1, F, int(W), C.byref(o), _ptr(sel) if len(sel) else None,
+                                          len(sel), int(N), out.ctypes.data, C.byref(n_out), _ptr(margin))
+        self._check(rc, "drl_al_get_samples")
+        idx = [int(i) for i in out[: n_out.value]]
+        return (idx, margin) if return_margin else idx
+
     # ------------------------------------------------------------------ measurement
     def profile(self, on: bool):
         self._check(self._lib.drl_profile_enable(self._h, 1 if on else 0), "drl_profile_enable")

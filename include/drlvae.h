@@ -176,6 +176,19 @@ int drl_rollout_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offs
                       const float* in_scale, const float* in_offset,
                       int32_t* action, float* q, int32_t* passes_out);
 
+/* ---- active-learning selection -------------------------------------------------------------------- */
+
+/* Replaces active_learning.get_samples (reference myasp-A1.py:250-259): scores every window
+ * (as drl_score_batch with the same series/opts), ranks them by the margin |q0-q1| ascending on
+ * the device (stable radix sort: equal margins keep ascending window order; np.argsort's
+ * quicksort leaves the order of exact ties unspecified), drops the indices in already_selected
+ * and returns the first N.  Host pointers, synchronous.
+ *   out_idx [N] window indices (concatenated-output numbering), *n_out = how many were written,
+ *   margin_out optional [K_total] = the margins themselves. */
+int drl_al_get_samples(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg, int F, int W,
+                       const drl_score_opts* opts, const int32_t* already_selected, int n_selected, int N,
+                       int32_t* out_idx, int32_t* n_out, float* margin_out);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* With profiling on, every kernel launch of the scoring path is bracketed by hipEvents on the

@@ -448,3 +448,27 @@ def test_f16x3_split_kernel_meets_the_fp32_tolerance(scorer, a1, ckpt_a1):
                               orc.rollout_greedy(s65, W, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"]))
     finally:
         scorer.set_lstm_math("fp32")
+
+
+# ----------------------------------------------------------------------------------- a-10 on device
+def test_al_selection_on_device(scorer, a1, ckpt_a1):
+    lstm, vae = ckpt_a1
+    scorer.set_lstm(lstm)
+    v = a1["series"][4]
+    K = len(v) - W
+    rng = np.random.default_rng(3)
+    already = sorted(set(int(i) for i in rng.choice(K, 200, replace=False)))
+    idx, margin = scorer.al_get_samples(v, W, 50, already, return_margin=True)
+    assert len(idx) == 50 and len(set(idx)) == 50 and not (set(idx) & set(already))
+    # exactly numpy's ranking of the device margins (stable order; margins are distinct here)
+    want = [int(i) for i in np.argsort(margin, kind="stable") if int(i) not in set(already)][:50]
+    assert idx == want
+    # and the oracle's selection up to margin rounding (reference myasp-A1.py:250-259)
+    r = orc.score_series_univariate(v, W, vae, lstm, "quirk", dtype=np.float64)
+    ref = orc.al_get_samples(r["q"], 50, already)
+    assert len(set(idx) & set(ref)) >= 48
+    np.testing.assert_allclose(margin, r["margin"], rtol=1e-4, atol=1e-5)
+    # N larger than what is left, and an empty request
+    few = scorer.al_get_samples(v[:W + 5], W, 50, [0, 1])
+    assert sorted(few) == [2, 3, 4]
+    assert scorer.al_get_samples(v, W, 0) == []
