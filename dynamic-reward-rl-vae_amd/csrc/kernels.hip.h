@@ -267,7 +267,16 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
 // are then LDS reads at lane stride F (conflict-free for odd F), RobustScaler/clip applied on the
 // fly.  The narrow middle layers chain in registers as in vae_kernel.
 #define VW_WT 4096     // floats per staged weight tile
+#ifndef VW_WAVES_PER_SIMD
+#define VW_WAVES_PER_SIMD 2
+#endif
+#ifndef VW_ABL
+#define VW_ABL 0      // timing-only ablations: 1 = every staged tile is tile 0 (L1/L2-hot loads), 2 = no loads
+#endif
 __device__ __forceinline__ void vw_stage_load(f32x4 (&reg)[4], const float* __restrict__ src) {
+#if VW_ABL == 2
+    return;
+#endif
     const f32x4* p = reinterpret_cast<const f32x4*>(src) + threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) reg[i] = p[i * 256];
@@ -288,8 +297,13 @@ __device__ __forceinline__ float vw_side_load(const VaeArgs& a, const float* __r
 
 // Hidden width is fixed at 4 tiles (97..128, zero padded) so that the 64 MFMAs of a weight tile
 // are straight-line code; SCALED selects the RobustScaler/clip transform at compile time.
+#if VW_ABL == 3
+#define VW_SYNC() do { } while (0)
+#else
+#define VW_SYNC() __syncthreads()
+#endif
 template <bool SCALED>
-__global__ __launch_bounds__(256, 1) void vae_wide_kernel(VaeArgs a, int xr_floats) {
+__global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArgs a, int xr_floats) {
     extern __shared__ __attribute__((aligned(16))) float vw_smem[];
     float* wt = vw_smem;                         // [2][VW_WT]
     float* side = vw_smem + 2 * VW_WT;           // [2][128]
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void vae_wide_kernel(VaeArgs a, int xr_floa
                 vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
                 if (threadIdx.x < 128) side[(cb ^ 1) * 128 + threadIdx.x] = side_next;
             }
-            __syncthreads();
+            VW_SYNC();
         }
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void vae_wide_kernel(VaeArgs a, int xr_floa
                 vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
                 if (threadIdx.x < 128) side[(cb ^ 1) * 128 + threadIdx.x] = side_next;
             }
-            __syncthreads();
+            VW_SYNC();
         }
         sq += __shfl_xor(sq, 32);
         if (active && a.err && half == 0 && j < count) a.err[wout] = sq / (float)D;
