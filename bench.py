@@ -194,10 +194,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # rehearsal of the N>1 path on a one-GPU box: DRLVAE_BENCH_REHEARSE=1 puts every rank on cuda:0 and
+    # swaps RCCL (which refuses two ranks on one device) for gloo.  Never a measurement.
+    rehearse = os.environ.get("DRLVAE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if rehearse else dev  # gloo has no GPU all_gather: the rehearsal stages through the host
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "c5" and not args.windows:
         args.windows = 4e6
@@ -219,7 +228,9 @@ def main():
                "margin": torch.empty(K, dtype=torch.float32, device=dev)}
         gathered = None
         if world > 1 and not args.no_allgather:
-            gathered = {k: torch.empty((world,) + tuple(v.shape), dtype=v.dtype, device=dev) for k, v in out.items()}
+            # rank r's windows land at rows [r*K, (r+1)*K) of every gathered array
+            gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=cdev)
+                        for k, v in out.items()}
     stream.synchronize()
 
     def step():
@@ -227,7 +238,7 @@ def main():
         if gathered is not None:
             with torch.cuda.stream(stream):
                 for k in out:
-                    dist.all_gather_into_tensor(gathered[k], out[k])
+                    dist.all_gather_into_tensor(gathered[k], out[k].cpu() if rehearse else out[k])
 
     def fence():
         stream.synchronize()
@@ -249,15 +260,16 @@ def main():
     lstm_ms, lstm_n = sc.profile_read(0)
     vae_ms, vae_n = sc.profile_read(1)
     sc.profile(False)
+    variant = sc.lstm_variant  # of the headline run (the alt run below changes it)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # the same workload once more with the other arithmetic of the H=128 recurrent product, reported
     # beside the headline (never as `value`): the 3-term compensated f16 split
     alt = None
-    if sc.lstm_variant.startswith("h128i2") and args.lstm_math == "fp32":
+    if variant.startswith("h128i2") and args.lstm_math == "fp32":
         sc.set_lstm_math("f16x3")
         for _ in range(max(1, args.warmup)):
             step()
@@ -272,7 +284,7 @@ def main():
         ms2, n2 = sc.profile_read(0)
         sc.profile(False)
         if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt2], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt2 = float(t.item())
         alt = {"lstm_math": "f16x3 (h.U as h_hi.U_hi + h_hi.U_lo + h_lo.U_hi on the f16 matrix pipe, fp32 accumulate; "
@@ -301,9 +313,10 @@ def main():
             "config": {"workload": wl["desc"], "windows_per_gpu_per_step": K, "window": wl["W"],
                        "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
-                       "collective": "rccl all_gather of err/q/action/margin" if gathered is not None else "none",
-                       "lstm_kernel": sc.lstm_variant},
-            "roofline": {"bound": "mfma", "kernel": "lstm_" + sc.lstm_variant,
+                       "collective": ("none" if gathered is None else "gloo all_gather (REHEARSAL, not a measurement)"
+                                      if rehearse else "rccl all_gather of err/q/action/margin"),
+                       "lstm_kernel": variant},
+            "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(wl["name"]),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
