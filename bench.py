@@ -222,23 +222,23 @@ def main():
     K, S = wl["K"], wl["S"]
     with torch.cuda.stream(stream):
         series = torch.from_numpy(wl["series"]).to(dev)
-        out = {"err": torch.empty(K, dtype=torch.float32, device=dev),
-               "q": torch.empty((K, S, 2), dtype=torch.float32, device=dev),
-               "action": torch.empty(K, dtype=torch.int32, device=dev),
-               "margin": torch.empty(K, dtype=torch.float32, device=dev)}
+        # one score record block per rank: [err K | q K*S*2 | action K (i32 bits) | margin K], 4-byte
+        # words, so that the whole result travels in ONE all-gather per step
+        words = K * (3 + 2 * S)
+        pack = torch.empty(words, dtype=torch.float32, device=dev)
+        out = {"err": pack[:K], "q": pack[K:K + 2 * S * K].view(K, S, 2),
+               "action": pack[K + 2 * S * K:2 * K + 2 * S * K].view(torch.int32), "margin": pack[2 * K + 2 * S * K:]}
         gathered = None
         if world > 1 and not args.no_allgather:
-            # rank r's windows land at rows [r*K, (r+1)*K) of every gathered array
-            gathered = {k: torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=cdev)
-                        for k, v in out.items()}
+            # rank r's block lands at words [r*words, (r+1)*words)
+            gathered = torch.empty(world * words, dtype=torch.float32, device=cdev)
     stream.synchronize()
 
     def step():
         sc.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
         if gathered is not None:
             with torch.cuda.stream(stream):
-                for k in out:
-                    dist.all_gather_into_tensor(gathered[k], out[k].cpu() if rehearse else out[k])
+                dist.all_gather_into_tensor(gathered, pack.cpu() if rehearse else pack)
 
     def fence():
         stream.synchronize()
@@ -314,7 +314,7 @@ def main():
                        "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
                        "collective": ("none" if gathered is None else "gloo all_gather (REHEARSAL, not a measurement)"
-                                      if rehearse else "rccl all_gather of err/q/action/margin"),
+                                      if rehearse else "one rccl all_gather of the packed err/q/action/margin block per step"),
                        "lstm_kernel": variant},
             "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
