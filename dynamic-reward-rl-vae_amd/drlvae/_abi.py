@@ -45,6 +45,28 @@ class ScoreOpts(C.Structure):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process can hold one HIP/HSA runtime.  PyTorch-ROCm wheels ship their own copy
+    (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and look it up by a file name the system
+    copy does not answer to, so a process that loads libdrlvae.so first and torch later would end up
+    with two runtimes and torch would see no GPU.  When torch is installed but not yet imported, map
+    its copy first: libdrlvae.so's NEEDED libamdhip64.so.7 then resolves to it by SONAME, whichever
+    order the caller imports things in.  Without torch the system runtime (RUNPATH /opt/rocm) is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads libdrlvae.so (built by __graft_entry__.build() / csrc/Makefile)."""
     global _lib
@@ -54,6 +76,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the scoring path.")
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.drl_create.argtypes = [C.c_int, C.POINTER(vp)]

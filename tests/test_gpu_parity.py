@@ -472,3 +472,86 @@ def test_al_selection_on_device(scorer, a1, ckpt_a1):
     few = scorer.al_get_samples(v[:W + 5], W, 50, [0, 1])
     assert sorted(few) == [2, 3, 4]
     assert scorer.al_get_samples(v, W, 0) == []
+
+
+# ----------------------------------------------------------------------------------- full sizes
+def _periodic_full_size(scorer, P, reps, F, Wn, vae, lstm, kw, want_first):
+    """BASELINE.json's full sizes, checked through a size-independent property: a series that
+    repeats with period P samples has windows that repeat with period P, and a window's score
+    does not depend on where in the stream (which tile, wave, lane, rank) it sits.  So every
+    period of the output must be BIT-identical to the first, and the first is checked against the
+    oracle to the usual tolerance."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(P)
+    base = rng.random((P, F), dtype=np.float32)
+    n = P * reps + Wn
+    series = torch.from_numpy(base).to(dev).repeat(reps + (Wn + P - 1) // P, 1)[:n].contiguous()
+    if F == 1:
+        series = series.reshape(-1)
+    K = n - Wn
+    S = 2 if kw.get("flag_mode") == "both" else 1
+    out = {"err": torch.empty(K, dtype=torch.float32, device=dev),
+           "q": torch.empty((K, S, 2), dtype=torch.float32, device=dev),
+           "action": torch.empty(K, dtype=torch.int32, device=dev),
+           "margin": torch.empty(K, dtype=torch.float32, device=dev)}
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    torch.cuda.synchronize()                           # the scorer launches on its own stream
+    scorer.score_dev(series, Wn, np.array([0, n], np.int64), out, **kw)
+    scorer.synchronize()
+    torch.cuda.synchronize()
+    assert K == P * reps
+    for k, t in out.items():
+        v = t.view(torch.int32).reshape(reps, -1)
+        assert bool((v == v[:1]).all()), f"{k}: a later period differs from the first"
+    first = {k: t[:P].cpu().numpy() for k, t in out.items()}
+    want = want_first(base, n)
+    np.testing.assert_allclose(first["err"], want["err"][:P], rtol=RTOL)
+    # Q of a window as one vector (all candidate states): norm-wise relative error.  The pair-wise
+    # form of assert_q_close sits at the fp32 noise floor for these random heads (the fp32 numpy
+    # oracle itself is 4e-6 from the fp64 one on this input).
+    q_want = np.asarray(want["q"][:P], np.float64).reshape(P, -1)
+    q_got = first["q"].astype(np.float64).reshape(P, -1)
+    rel = np.abs(q_got - q_want).max(axis=1) / np.abs(q_want).max(axis=1)
+    assert rel.max() <= RTOL, f"Q: max norm-wise rel diff {rel.max():.3e}"
+    return first
+
+
+def test_c5_full_size_stream_is_periodic(scorer):
+    """C5 at its full per-GPU size: 1.25e8 windows, W = 50, one launch (index arithmetic beyond
+    2^31 bytes of output, 488,282 tiles)."""
+    rng = np.random.default_rng(5)
+    vae = synth_vae(rng, [50, 64, 64, 64, 10, 64, 50], 3)
+    lstm = synth_lstm(rng, 2, 128)
+    P, reps = 1000, 125_000
+
+    def want_first(base, n):
+        v = np.tile(base.reshape(-1), 2)[:P + 50]
+        return orc.score_series_univariate(v, 50, vae, lstm, "zeros", dtype=np.float64)
+
+    _periodic_full_size(scorer, P, reps, 1, 50, vae, lstm, dict(flag_mode="zeros"), want_first)
+    assert scorer.lstm_variant == "h128i2"
+
+
+@pytest.mark.parametrize("F,N", [(38, 28_479), (123, 172_801)])
+def test_c3_c4_full_size_series_are_periodic(scorer, F, N):
+    """C3 / C4 at the series lengths SURVEY.md §8d names (SMD machine-1-1, WaDi), WaDi formulation."""
+    rng = np.random.default_rng(F)
+    D = W * F
+    vae = synth_vae(rng, [D, 128, 10, 128, D], 1)
+    lstm = synth_lstm(rng, F + 1, 64)
+    P = 173
+    reps = (N - W) // P
+    center = rng.uniform(0.3, 0.7, D).astype(np.float32)
+    scale = rng.uniform(0.2, 0.6, D).astype(np.float32)
+
+    def want_first(base, n):
+        x = np.tile(base, (2, 1))[:P + W]
+        return orc.score_series_multivariate(x, W, vae, lstm, center, scale, 10.0, dtype=np.float64)
+
+    first = _periodic_full_size(scorer, P, reps, F, W, vae, lstm,
+                                dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=center,
+                                     vae_scale=scale, vae_clip=10.0), want_first)
+    assert scorer.lstm_variant == "xproj+rec"
+    assert first["q"].shape == (P, 2, 2)
