@@ -123,6 +123,7 @@ int ensure_pinned(drl_ctx* c, size_t bytes) {
 
 inline int rowmap_h(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 inline size_t up16(size_t n) { return (n + 15) & ~size_t(15); }
+inline size_t up32(size_t n) { return (n + 31) & ~size_t(31); }
 
 // Dense layer K [din,dout] -> A fragments [out_tile][in_tile][16][64]:
 // lane l of k-step r holds K[in = it*32 + rowmap(r, l>>5)][out = ot*32 + (l&31)] (0 outside).
@@ -539,7 +540,7 @@ struct OptDev {
 int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d) {
     size_t n = 0;
     if (o->in_scale) n += 2 * up16(n_seg);
-    if (o->vae_center) n += 3 * up16(D);
+    if (o->vae_center) n += 3 * up32(D);
     if (!n) return DRL_OK;
     int rc = ensure(c, c->opt, n * sizeof(float));
     if (rc) return rc;
@@ -555,14 +556,17 @@ int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d
     }
     if (o->vae_center) {
         if (!o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
-        HIP_TRY(c, hipMemcpyAsync(base + off, o->vae_center, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        d.center = base + off; off += up16(D);
-        HIP_TRY(c, hipMemcpyAsync(base + off, o->vae_scale, D * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        d.scale = base + off; off += up16(D);
-        std::vector<float> inv(D);
-        for (int i = 0; i < D; ++i) inv[i] = (float)(1.0 / (double)o->vae_scale[i]);
-        HIP_TRY(c, hipMemcpy(base + off, inv.data(), D * sizeof(float), hipMemcpyHostToDevice));
-        d.inv_scale = base + off; off += up16(D);
+        // padded to a whole 32-feature tile (center 0, scale 1): vae_wide_kernel streams them per tile
+        const size_t P = up32(D);
+        std::vector<float> h(3 * P);
+        for (size_t i = 0; i < P; ++i) {
+            const bool in = i < (size_t)D;
+            h[i] = in ? o->vae_center[i] : 0.0f;
+            h[P + i] = in ? o->vae_scale[i] : 1.0f;
+            h[2 * P + i] = in ? (float)(1.0 / (double)o->vae_scale[i]) : 1.0f;
+        }
+        HIP_TRY(c, hipMemcpy(base + off, h.data(), 3 * P * sizeof(float), hipMemcpyHostToDevice));
+        d.center = base + off; d.scale = base + off + P; d.inv_scale = base + off + 2 * P; off += 3 * P;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DRL_OK;

@@ -114,6 +114,20 @@ __device__ __forceinline__ float apply_act(float y, int act) {
     return y;
 }
 
+// Activation of a whole accumulator tile with the (wave-uniform, run-time) code tested ONCE: a
+// per-element apply_act(y, act) leaves a chain of scalar branches around every element, which
+// serialises the transcendental latencies.
+template <int ACT>
+__device__ __forceinline__ void act16_ct(f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], ACT);
+}
+__device__ __forceinline__ void act16(f32x16& v, int act) {
+    if (act == 1) act16_ct<1>(v);
+    else if (act == 2) act16_ct<2>(v);
+    else if (act == 3) act16_ct<3>(v);
+}
+
 __device__ __forceinline__ f32x16 load_bias16(const float* __restrict__ bp, int tile, int half) {
     const f32x4* p = reinterpret_cast<const f32x4*>(bp + (tile * 2 + half) * 16);
     f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -176,9 +190,7 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
             }
         }
 #pragma unroll
-        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(cur[ot][r], a.act[0]);
+        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot) act16(cur[ot], a.act[0]);
     }
 
     // ---- middle layers: registers -> registers
@@ -206,9 +218,7 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
             }
         }
 #pragma unroll
-        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(nxt[ot][r], a.act[p]);
+        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot) { cur[ot] = nxt[ot]; act16(cur[ot], a.act[p]); }
         if (with_lv) {
             // z = mu + exp(0.5*clip(logvar))*eps   (reference myasp-A1.py:84, 94)
 #pragma unroll
@@ -239,10 +249,11 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
                         acc = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], acc);
                 }
             }
+            act16(acc, a.act[p]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = ot * 32 + rowmap(r, half);
-                const float y = apply_act(acc[r], a.act[p]);
+                const float y = acc[r];
                 const float xv = vae_input(a, xin, d, has_norm, sc, of);
                 if (d < a.D) {
                     const float df = y - xv;
@@ -271,7 +282,8 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
 #define VW_WAVES_PER_SIMD 2
 #endif
 #ifndef VW_ABL
-#define VW_ABL 0      // timing-only ablations: 1 = every staged tile is tile 0 (L1/L2-hot loads), 2 = no loads
+#define VW_ABL 0      // timing-only ablations (wrong results): 1 every staged tile is tile 0, 2 no global loads,
+                      // 3 no barriers, 4 no last-layer epilogue, 5 no layer-0 input transform
 #endif
 __device__ __forceinline__ void vw_stage_load(f32x4 (&reg)[4], const float* __restrict__ src) {
 #if VW_ABL == 2
@@ -286,13 +298,17 @@ __device__ __forceinline__ void vw_stage_store(const f32x4 (&reg)[4], float* dst
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i * 256] = reg[i];
 }
-// side tile: center[32] | inv_scale[32] | packed bias[32] of feature tile `ft`
-__device__ __forceinline__ float vw_side_load(const VaeArgs& a, const float* __restrict__ bias_p, int ft) {
+// side tile of feature tile `ft`: center[32] | inv_scale[32] | packed bias[32].  Every thread owns
+// one stream (a base pointer chosen once, advanced 32 floats per tile) so the per-tile load is a
+// single unconditional global_load: center/inv_scale are padded to a multiple of 32 on the host
+// (pad: center 0, inv_scale 1) and the packed bias is tile-padded by construction.  Threads with
+// nothing to fetch re-read a valid dummy word.
+__device__ __forceinline__ const float* vw_side_stream(const VaeArgs& a, const float* __restrict__ bias_p, bool scaled) {
     const int t = threadIdx.x;
-    if (t < 32) { const int d = ft * 32 + t; return (a.center && d < a.D) ? a.center[d] : 0.0f; }
-    if (t < 64) { const int d = ft * 32 + t - 32; return (a.center && d < a.D) ? a.inv_scale[d] : 1.0f; }
-    if (t < 96) return bias_p ? bias_p[ft * 32 + t - 64] : 0.0f;
-    return 0.0f;
+    if (scaled && t < 32) return a.center + t;
+    if (scaled && t < 64) return a.inv_scale + (t - 32);
+    if (bias_p && t >= 64 && t < 96) return bias_p + (t - 64);
+    return a.w[0];
 }
 
 // Hidden width is fixed at 4 tiles (97..128, zero padded) so that the 64 MFMAs of a weight tile
@@ -352,17 +368,18 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
         const float* __restrict__ w = a.w[0];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) cur[ot] = load_bias16(a.b[0], ot, half);
+        const float* __restrict__ ss = vw_side_stream(a, nullptr, SCALED);
         vw_stage_load(stg, w);
         vw_stage_store(stg, wt);
-        if (threadIdx.x < 128) side[threadIdx.x] = vw_side_load(a, nullptr, 0);
+        if (threadIdx.x < 128) side[threadIdx.x] = ss[0];
         __syncthreads();
         for (int it = 0; it < nin; ++it) {
             const int cb = it & 1;
             const bool more = it + 1 < nin;
             float side_next = 0.0f;
             if (more) {
+                if (SCALED) side_next = ss[(it + 1) * 32];
                 vw_stage_load(stg, w + (size_t)(it + 1) * VW_WT);
-                if (threadIdx.x < 128) side_next = vw_side_load(a, nullptr, it + 1);
             }
             if (active) {
                 const float* __restrict__ wb = wt + cb * VW_WT + lane;
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
                 for (int r = 0; r < 16; ++r) {
                     const int dl = rowmap(r, half);
                     float bv = xt[dl];
-                    if (SCALED) bv = fminf(fmaxf((bv - sb[dl]) * sb[32 + dl], -clip), clip);
+                    if (SCALED && VW_ABL != 5) bv = fminf(fmaxf((bv - sb[dl]) * sb[32 + dl], -clip), clip);
 #pragma unroll
                     for (int ot = 0; ot < 4; ++ot) cur[ot] = mfma32(wb[(ot * 16 + r) * 64], bv, cur[ot]);
                 }
@@ -384,9 +401,7 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
             VW_SYNC();
         }
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(cur[ot][r], a.act[0]);
+        for (int ot = 0; ot < 4; ++ot) act16(cur[ot], a.act[0]);
     }
 
     // ---- middle layers: registers -> registers, small weights straight from L2
@@ -410,9 +425,7 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
                 }
             }
 #pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cur[ot][r] = apply_act(nxt[ot][r], a.act[p]);
+            for (int ot = 0; ot < 4; ++ot) { cur[ot] = nxt[ot]; act16(cur[ot], a.act[p]); }
         }
     }
 
@@ -423,17 +436,18 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
         const float* __restrict__ w = a.w[p];
         const int act = a.act[p];
         float sq = 0.0f;
+        const float* __restrict__ ss = vw_side_stream(a, a.b[p], SCALED);
         vw_stage_load(stg, w);
         vw_stage_store(stg, wt);
-        if (threadIdx.x < 128) side[threadIdx.x] = vw_side_load(a, a.b[p], 0);
+        if (threadIdx.x < 128) side[threadIdx.x] = ss[0];
         __syncthreads();
         for (int ot = 0; ot < nout; ++ot) {
             const int cb = ot & 1;
             const bool more = ot + 1 < nout;
             float side_next = 0.0f;
             if (more) {
+                side_next = ss[(ot + 1) * 32];
                 vw_stage_load(stg, w + (size_t)(ot + 1) * VW_WT);
-                if (threadIdx.x < 128) side_next = vw_side_load(a, a.b[p], ot + 1);
             }
             if (active) {
                 const float* __restrict__ wb = wt + cb * VW_WT + lane;
@@ -444,15 +458,20 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc = mfma32(wb[(it * 16 + r) * 64], cur[it][r], acc);
+#if VW_ABL == 4
+                sq += acc[0] + acc[15];
+#else
+                act16(acc, act);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dl = rowmap(r, half);
-                    const float y = apply_act(acc[r], act);
+                    const float y = acc[r];
                     float xv = xt[dl];
                     if (SCALED) xv = fminf(fmaxf((xv - sb[dl]) * sb[32 + dl], -clip), clip);
                     const float df = (ot * 32 + dl < D) ? y - xv : 0.0f;
                     sq = fmaf(df, df, sq);
                 }
+#endif
             }
             if (more) {
                 vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
