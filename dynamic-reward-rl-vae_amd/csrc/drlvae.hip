@@ -672,14 +672,16 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
         } else if (c->lstm.NT == 8 && !od.in_scale &&
-                   (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)16 << 30)) {   // projections: 1 KiB per sample
+                   (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)64 << 30)) {   // projections: 1 KiB per sample (a chunk stays < 4 GiB)
             // H <= 64: project every sample once, then run the recurrences from the projections
             const long long n_samples = seg_offsets[n_seg];
             const size_t pbytes = (size_t)n_samples * 8 * 32 * sizeof(float);
             if ((rc = ensure(c, c->pbuf, pbytes))) return rc;
-            const size_t lds = (size_t)32 * 8 * 64 * sizeof(float);
+            const size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);   // U + the flag row
             if (!c->rec_attr_set) {
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 c->rec_attr_set = true;
             }
@@ -691,7 +693,10 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             a.n_tiles = sh.tiles32;
             ra.l = a; ra.P = xa.P; ra.n_samples = n_samples;
             ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
-            hipLaunchKernelGGL(lstm_rec_kernel<8>, dim3((sh.tiles32 + 3) / 4, a.S), dim3(256), lds, c->stream, ra);
+            // S == 2: a workgroup is 2 tiles x 2 candidates; S == 1: 4 tiles
+            const unsigned rec_grid = a.S == 2 ? (sh.tiles32 + 1) / 2 : (sh.tiles32 + 3) / 4;
+            if (a.flag_mode > 0) hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
+            else hipLaunchKernelGGL((lstm_rec_kernel<8, false>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
             c->last_variant = "xproj+rec";
         } else {
             a.n_tiles = sh.tiles32;

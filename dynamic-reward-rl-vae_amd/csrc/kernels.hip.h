@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
                 for (int r = 0; r < 16; ++r) {
                     const int dl = rowmap(r, half);
                     float bv = xt[dl];
-                    if (SCALED && VW_ABL != 5) bv = fminf(fmaxf((bv - sb[dl]) * sb[32 + dl], -clip), clip);
+                    if (SCALED && VW_ABL != 5) bv = __builtin_amdgcn_fmed3f((bv - sb[dl]) * sb[32 + dl], -clip, clip);
 #pragma unroll
                     for (int ot = 0; ot < 4; ++ot) cur[ot] = mfma32(wb[(ot * 16 + r) * 64], bv, cur[ot]);
                 }
@@ -453,22 +453,33 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
                 const float* __restrict__ wb = wt + cb * VW_WT + lane;
                 const float* __restrict__ sb = side + cb * 128;
                 const float* __restrict__ xt = xw + ot * 32;
+                // everything the tile reads from LDS is requested before its first MFMA (bias first,
+                // it initialises the accumulator), so the LDS latency is paid once per tile and the
+                // epilogue's operands arrive under the MFMAs
                 f32x16 acc = load_bias16(sb + 64, 0, half);
+                float av[64], xv[16], cen[16], isc[16];
+#pragma unroll
+                for (int i = 0; i < 64; ++i) av[i] = wb[i * 64];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dl = rowmap(r, half);
+                    xv[r] = xt[dl];
+                    if (SCALED) { cen[r] = sb[dl]; isc[r] = sb[32 + dl]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc = mfma32(wb[(it * 16 + r) * 64], cur[it][r], acc);
+                    for (int r = 0; r < 16; ++r) acc = mfma32(av[it * 16 + r], cur[it][r], acc);
 #if VW_ABL == 4
-                sq += acc[0] + acc[15];
+                sq += acc[0] + acc[15] + xv[0];
 #else
                 act16(acc, act);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int dl = rowmap(r, half);
-                    const float y = acc[r];
-                    float xv = xt[dl];
-                    if (SCALED) xv = fminf(fmaxf((xv - sb[dl]) * sb[32 + dl], -clip), clip);
-                    const float df = (ot * 32 + dl < D) ? y - xv : 0.0f;
+                    float x = xv[r];
+                    if (SCALED) x = __builtin_amdgcn_fmed3f((x - cen[r]) * isc[r], -clip, clip);
+                    const float df = (ot * 32 + rowmap(r, half) < D) ? acc[r] - x : 0.0f;
                     sq = fmaf(df, df, sq);
                 }
 #endif
@@ -623,16 +634,17 @@ __global__ __launch_bounds__(256, 1) void lstm_generic_kernel(LstmArgs a) {
 // candidate states, so it is computed ONCE per sample (xproj_kernel) instead of W*S times, and
 // the recurrence (lstm_rec_kernel) starts every step from it.
 //
-// P layout: [chunk = (tile*2 + half)*4 + rg][sample][4 floats] where the 4 floats are accumulator
-// registers 4rg..4rg+3 of (tile, half) — i.e. the four gates i,j,f,o of one hidden unit.  Both the
-// producer's stores and the consumer's loads are then 512 contiguous bytes per half-wave.
+// P layout: [chunk = tile*4 + rg][sample][half][4 floats] where the 4 floats are accumulator
+// registers 4rg..4rg+3 of (tile, half) — i.e. the four gates i,j,f,o of one hidden unit.  A wave's
+// store (producer) or load (consumer) of one chunk is then 2 KiB contiguous, and the chunk index
+// is wave-uniform: the consumer addresses it as a scalar base + one 32-bit lane offset.
 struct XprojArgs {
     const float* x;          // [n_samples, F]
     long long n_samples;
     int F;
     const float* wx;         // packed [ceil(I/2)][NT][64] (the flag row, feature F, is skipped here)
     const float* bias;       // packed [NT][2][16]
-    float* P;                // [NT*8][n_samples][4]
+    float* P;                // [NT*4][n_samples][2][4]
 };
 
 template <int NT>
@@ -661,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void xproj_kernel(XprojArgs a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 f32x4 v = {acc[tl][4 * rg], acc[tl][4 * rg + 1], acc[tl][4 * rg + 2], acc[tl][4 * rg + 3]};
-                *reinterpret_cast<f32x4*>(a.P + (((size_t)(tl * 2 + half) * 4 + rg) * a.n_samples + (n0 + j)) * 4) = v;
+                *reinterpret_cast<f32x4*>(a.P + ((((size_t)tl * 4 + rg) * a.n_samples + (n0 + j)) * 2 + half) * 4) = v;
             }
     }
 }
@@ -673,25 +685,91 @@ struct RecArgs {
     const float* flagw;      // packed [NT][2][16]: the flag row of Wx in accumulator order
 };
 
-// 4 waves per workgroup (one per SIMD, the whole register file), each an independent 32-window x 1-candidate recurrence: U (<= 64 KiB)
-// is shared through LDS as A fragments, h_t feeds step t+1 straight from the registers it was
-// computed into (accumulator order == B-operand order), c never leaves registers, no barriers
-// after the weights are staged.
+// 4 waves per workgroup (one per SIMD), each an independent 32-window x 1-candidate recurrence:
+// U (<= 64 KiB) is shared through LDS as A fragments, h_t feeds step t+1 straight from registers
+// (accumulator order == B-operand order), c never leaves registers, no barriers after the weights
+// are staged.
+//  * With two candidate states (WaDi rule) the waves of a workgroup are {tile, tile+1} x {a0, a1}:
+//    both candidates read the same projections, so the second one hits in the CU's own cache.
+//  * A step walks the gate tiles one after the other (one 16-register accumulator, a chain of 4*NT
+//    MFMAs, then the cell update of that tile's 8 units), so the projections are needed one tile
+//    at a time: a 4-slot ring requests tile tl+4 when tile tl is consumed, half a step ahead.
+//  * A fragments come from LDS in groups of 8, one group ahead of their MFMAs, across tile
+//    boundaries too, so the MFMA stream does not drain at a boundary.
 template <int NT>
+__device__ __forceinline__ f32x16 rec_load_p(const char* __restrict__ P, size_t chunk_bytes, unsigned voff, int tl) {
+    f32x16 d;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const char* base = P + (size_t)(tl * 4 + rg) * chunk_bytes;          // wave-uniform
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + voff);       // + 32-bit lane offset
+        d[4 * rg] = v[0]; d[4 * rg + 1] = v[1]; d[4 * rg + 2] = v[2]; d[4 * rg + 3] = v[3];
+    }
+    return d;
+}
+
+// One step of one wave.  FIRST: h = 0, so only the projections (and the flag term) enter the cell.
+template <int NT, bool FLAGGED, bool FIRST>
+__device__ __forceinline__ void rec_step(f32x16 (&pq)[4], float (&aq)[2][8], float (&c)[NT][4], float (&h)[NT][4],
+                                         const float* __restrict__ ul, const float* __restrict__ s_fw,
+                                         const char* __restrict__ Pb, size_t chunk_bytes, unsigned voff_t,
+                                         unsigned voff_n, float fl, int half) {
+    float hn[NT][4];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        f32x16 acc = pq[tl & 3];
+        // refill the slot: tile tl+4 of this step, or tile tl+4-NT of the next one
+        pq[tl & 3] = (tl + 4 < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + 4)
+                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + 4 - NT);
+        if (FLAGGED) {
+            const f32x16 wf = load_bias16(s_fw, tl, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(fl, wf[r], acc[r]);
+        }
+        if (!FIRST) {
+#pragma unroll
+            for (int g = 0; g < NT / 2; ++g) {
+                // next group of A fragments: same tile, or group 0 of the next tile (tile 0 after the last)
+                const int ng = (g + 1) % (NT / 2), ntl = (g + 1 < NT / 2) ? tl : (tl + 1) % NT;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) aq[(g + 1) & 1][i] = ul[((ng * 8 + i) * NT + ntl) * 64];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = g * 8 + i;
+                    acc = mfma32(aq[g & 1][i], h[kk >> 2][kk & 3], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            hn[tl][qd] = lstm_cell(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3], 0.0f, c[tl][qd]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) h[tl][qd] = hn[tl][qd];
+}
+
+template <int NT, bool FLAGGED>
 __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(RecArgs ra) {
-    extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64]
+    extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64] | flag row [NT][2][16]
+    static_assert(NT % 4 == 0, "the projection ring assumes a multiple of 4 gate tiles");
     const LstmArgs& a = ra.l;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
+    float* s_fw = rec_u + NT * 4 * NT * 64;
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.u);
         f32x4* dst = reinterpret_cast<f32x4*>(rec_u);
         for (int i = threadIdx.x; i < NT * 4 * NT * 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < NT * 32; i += 256) s_fw[i] = ra.flagw[i];
     }
     __syncthreads();
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = a.S == 2 ? blockIdx.x * 2 + (wave >> 1) : blockIdx.x * 4 + wave;
+    const int cand = a.S == 2 ? (wave & 1) : 0;
     if (tile >= a.n_tiles) return;
-    const int cand = blockIdx.y;
     const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
     const long long samp0 = a.seg.samp_off[s];
     const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
@@ -701,67 +779,37 @@ __global__ __launch_bounds__(256, 1) void lstm_rec_kernel(RecArgs ra) {
     const long long k = k0 + jj;
     const long long nrow0 = samp0 + a.row0 + k;            // sample of row 0 of this lane's window
     const float* __restrict__ ul = rec_u + lane;
+    // one chunk of P is n_samples*32 bytes (< 4 GiB, checked by the host): 32-bit lane offsets
+    // against 4*NT uniform chunk bases
+    const char* __restrict__ Pb = reinterpret_cast<const char*>(ra.P);
+    const size_t chunk_bytes = (size_t)ra.n_samples * 32;
+    const unsigned voff0 = (unsigned)((size_t)nrow0 * 32 + half * 16);
+    const int W = a.W;
 
-    f32x16 acc[NT];
+    f32x16 pq[4];
     float c[NT][4], h[NT][4];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) { c[tl][qd] = 0.0f; h[tl][qd] = 0.0f; }
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) pq[tl] = rec_load_p<NT>(Pb, chunk_bytes, voff0, tl);
+    float aq[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aq[0][i] = ul[(i * NT + 0) * 64];
 
-    for (int t = 0; t < a.W; ++t) {
-        // z = P[sample] (+ flag * wf)
-        const float* __restrict__ pp = ra.P + (size_t)(nrow0 + t) * 4;
-#pragma unroll
-        for (int tl = 0; tl < NT; ++tl)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(pp + ((size_t)(tl * 2 + half) * 4 + rg) * ra.n_samples * 4);
-                acc[tl][4 * rg] = v[0]; acc[tl][4 * rg + 1] = v[1]; acc[tl][4 * rg + 2] = v[2]; acc[tl][4 * rg + 3] = v[3];
-            }
-        if (a.flag_mode == 3) {
-            if (cand) {
-#pragma unroll
-                for (int tl = 0; tl < NT; ++tl) acc[tl] += load_bias16(ra.flagw, tl, half);
-            }
-        } else if (a.flag_mode > 0) {
-            const float fl = synth_flag(a.flag_mode, k, t, a.W, cand, a.flags, nrow0 + t);
-#pragma unroll
-            for (int tl = 0; tl < NT; ++tl) {
-                const f32x16 wf = load_bias16(ra.flagw, tl, half);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tl][r] = fmaf(fl, wf[r], acc[tl][r]);
-            }
-        }
-        if (t > 0) {
-            // A fragments one k-step ahead of their MFMAs, and no further (bounded registers)
-            float ua[NT], ub[NT];
-#pragma unroll
-            for (int tl = 0; tl < NT; ++tl) ua[tl] = ul[tl * 64];
-#pragma unroll
-            for (int kk = 0; kk < NT * 4; kk += 2) {
-#pragma unroll
-                for (int tl = 0; tl < NT; ++tl) ub[tl] = ul[((kk + 1) * NT + tl) * 64];
-#pragma unroll
-                for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(ua[tl], h[kk >> 2][kk & 3], acc[tl]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk + 2 < NT * 4) {
-#pragma unroll
-                    for (int tl = 0; tl < NT; ++tl) ua[tl] = ul[((kk + 2) * NT + tl) * 64];
-                }
-#pragma unroll
-                for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(ub[tl], h[(kk + 1) >> 2][(kk + 1) & 3], acc[tl]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int tl = 0; tl < NT; ++tl) {
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-                h[tl][qd] = lstm_cell(acc[tl][4 * qd], acc[tl][4 * qd + 1], acc[tl][4 * qd + 2],
-                                      acc[tl][4 * qd + 3], 0.0f, c[tl][qd]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    auto flag_of = [&](int t) -> float {
+        if (!FLAGGED) return 0.0f;
+        if (a.flag_mode == 3) return (float)cand;
+        return synth_flag(a.flag_mode, k, t, W, cand, a.flags, nrow0 + t);
+    };
+    // the ring's last refill of the last step re-reads that step (W-1 clamps): harmless, branch-free
+    rec_step<NT, FLAGGED, true>(pq, aq, c, h, ul, s_fw, Pb, chunk_bytes, voff0,
+                                voff0 + (unsigned)(1 < W ? 1 : 0) * 32u, flag_of(0), half);
+    for (int t = 1; t < W; ++t) {
+        const int tn = t + 1 < W ? t + 1 : t;
+        rec_step<NT, FLAGGED, false>(pq, aq, c, h, ul, s_fw, Pb, chunk_bytes, voff0 + (unsigned)t * 32u,
+                                     voff0 + (unsigned)tn * 32u, flag_of(t), half);
     }
 
     for (int act = 0; act < a.A; ++act) {

@@ -4,7 +4,7 @@
 k=$1; shift
 d=$(mktemp -d /tmp/asmstat.XXXX)
 cd "$(dirname "$0")/../dynamic-reward-rl-vae_amd/csrc"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed "$@" -save-temps=obj -c -o $d/x.o drlvae.hip 2>$d/err || { cat $d/err; exit 1; }
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -save-temps=obj -c -o $d/x.o drlvae.hip 2>$d/err || { cat $d/err; exit 1; }
 S=$d/drlvae-hip-amdgcn-amd-amdhsa-gfx950.s
 sym=$(grep -o "^_Z[A-Za-z0-9_]*$k[A-Za-z0-9_]*:" $S | head -1 | tr -d :)
 awk "/^$sym:/,/s_endpgm/" $S > $d/k.s

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../dynamic-reward-rl-vae_amd/csrc"
 mkdir -p ../../build
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed $flags \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form=1 $flags \
       -o ../../build/libdrlvae_$name.so drlvae.hip &
 done
 wait
