@@ -58,6 +58,7 @@ struct Prof {
 
 struct drl_ctx {
     int device = 0;
+    int n_cu = 256;               // compute units: size of the persistent grids
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -305,6 +306,7 @@ int drl_create(int device_id, drl_ctx** out) {
     if (e != hipSuccess) return fail(nullptr, DRL_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     drl_ctx* c = new drl_ctx();
     c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -665,11 +667,12 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.l = a;
             fa.uhi = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.uhi_off);
             fa.ulo = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.ulo_off);
-            hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, fa);
+            hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
             c->last_variant = "h128i2_f16x3";
         } else if (fast) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
-            hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(sh.tiles64, a.S), dim3(256), 0, c->stream, a);
+            // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
+            hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
         } else if (c->lstm.NT == 8 && !od.in_scale &&
                    (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)64 << 30)) {   // projections: 1 KiB per sample (a chunk stays < 4 GiB)

@@ -68,6 +68,36 @@ __device__ __forceinline__ int find_seg(const int* __restrict__ tile_off, int n_
     return lo;
 }
 
+// Persistent kernels look a tile's series up once per tile; out of global memory that is a chain of
+// ~log2(n_seg)+2 dependent loads (microseconds).  Up to SEG_LDS series the tables are copied to LDS
+// once per workgroup instead.
+#define SEG_LDS 512
+struct SegLds {
+    long long samp[SEG_LDS + 1];
+    long long win[SEG_LDS + 1];
+    int toff[SEG_LDS + 1];
+};
+struct SegHit { int s; long long samp0, nsamp, win0, Ks; int tile0; };
+__device__ __forceinline__ void seg_stage(SegLds& d, const SegTab& seg) {
+    if (seg.n_seg > SEG_LDS) return;
+    for (int i = threadIdx.x; i <= seg.n_seg; i += blockDim.x) {
+        d.samp[i] = seg.samp_off[i]; d.win[i] = seg.win_off[i]; d.toff[i] = seg.tile_off[i];
+    }
+}
+__device__ __forceinline__ SegHit seg_lookup(const SegLds& d, const SegTab& seg, int tile) {
+    SegHit h;
+    if (seg.n_seg <= SEG_LDS) {
+        h.s = find_seg(d.toff, seg.n_seg, tile);
+        h.samp0 = d.samp[h.s]; h.nsamp = d.samp[h.s + 1] - h.samp0;
+        h.win0 = d.win[h.s]; h.Ks = d.win[h.s + 1] - h.win0; h.tile0 = d.toff[h.s];
+    } else {
+        h.s = find_seg(seg.tile_off, seg.n_seg, tile);
+        h.samp0 = seg.samp_off[h.s]; h.nsamp = seg.samp_off[h.s + 1] - h.samp0;
+        h.win0 = seg.win_off[h.s]; h.Ks = seg.win_off[h.s + 1] - h.win0; h.tile0 = seg.tile_off[h.s];
+    }
+    return h;
+}
+
 // reference env.py:78-79 (sklearn MinMaxScaler): x*scale_ + min_ with two float32 roundings
 __device__ __forceinline__ float minmax_apply(float x, float sc, float of) {
     float m = x * sc;
@@ -888,7 +918,7 @@ __device__ __forceinline__ void h128_pointwise(const f32x16 (&acc)[4], float (&c
 }
 
 #ifndef H128_ABL
-#define H128_ABL 0        // timing-only ablations (wrong results): 2 no barriers
+#define H128_ABL 0        // timing-only ablations (wrong results): 2 no barriers, 3 prologue only
 #endif
 #if H128_ABL == 2
 #define H128_SYNC() do { } while (0)
@@ -904,100 +934,122 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float s_u[4][(4 - H128_UREG) * 64 * 64 + 4];   // per wave: U of its last tile(s)
     __shared__ float s_sv[H128_SV];          // normalised samples k0 .. k0+64+W
     __shared__ float s_sf[H128_SV];          // explicit flags of those samples
+    __shared__ float s_wout[128 * 8];        // Q head, [unit][action]
+    __shared__ SegLds s_seg;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
-    const int tile = blockIdx.x;
     const int cand = blockIdx.y;
     const int W = a.W;
-    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
-    const long long samp0 = a.seg.samp_off[s];
-    const long long nsamp = a.seg.samp_off[s + 1] - samp0;
-    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
-    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 64;
-    const int count = (int)(Ks - k0 < 64 ? Ks - k0 : 64);
+    seg_stage(s_seg, a.seg);
+    for (int i = threadIdx.x; i < 128 * a.A; i += 256) s_wout[i] = a.w_out[i];
 
-    // stage the series tile (and explicit flags) into LDS, coalesced, clamped to the series
-    {
-        const bool has_norm = a.seg.in_scale != nullptr;
-        const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
-        const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
-        for (int i = threadIdx.x; i < 64 + W + 1 && i < H128_SV; i += 256) {
-            long long n = k0 + i;
-            if (n > nsamp - 1) n = nsamp - 1;
-            float v = a.x[samp0 + n];
-            if (has_norm) v = minmax_apply(v, sc, of);
-            s_sv[i] = v;
-            s_sf[i] = (a.flag_mode == 2) ? a.flags[samp0 + n] : 0.0f;
-        }
-        for (int i = threadIdx.x; i < 16 * 2 * 16; i += 256) s_bias[i] = a.bias[i];
-    }
-
-    // weights to registers
+    // weights to registers, ONCE per workgroup: the grid is persistent (one workgroup per CU walks
+    // tiles blockIdx.x, +gridDim.x, ...), because every workgroup of a wave of launches would
+    // otherwise pull the same 256 KiB through the same L2 channels at the same moment
     float U[H128_UREG][64], wx[4];
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) wx[tl] = a.wx[(4 * w + tl) * 64 + lane];
+    // a tile's 64 loads are all in flight before the first value is pinned: load -> wait -> pin, one
+    // value at a time, costs 192 round trips to L2 (60 us per workgroup)
 #pragma unroll
-    for (int tl = 0; tl < H128_UREG; ++tl)
+    for (int tl = 0; tl < H128_UREG; ++tl) {
+        float tmp[64];
 #pragma unroll
-        for (int kk = 0; kk < 64; ++kk) U[tl][kk] = pin_agpr(a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane]);
+        for (int kk = 0; kk < 64; ++kk) tmp[kk] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) U[tl][kk] = pin_agpr(tmp[kk]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float* ul = &s_u[w][0];
-    for (int tl = H128_UREG; tl < 4; ++tl)
+    for (int tl = H128_UREG; tl < 4; ++tl) {
+#pragma unroll 16
         for (int kk = 0; kk < 64; ++kk)
             ul[((tl - H128_UREG) * 64 + kk) * 64 + lane] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
-    __syncthreads();
-
+    }
+    for (int i = threadIdx.x; i < 16 * 2 * 16; i += 256) s_bias[i] = a.bias[i];
     const float* bias_l = s_bias;
     float* hA = s_hA;
     float* hB = s_hB;
     const float fb = a.forget_bias;
-    f32x16 accA[4], accB[4];
-    float cA[4][4], cB[4][4];
-#pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) { cA[tl][qd] = 0.0f; cB[tl][qd] = 0.0f; }
-
-    // B operand of the input k-step: lanes 0-31 carry the value, lanes 32-63 the flag
-    auto xin = [&](int g, int t) -> float {
-        const int li = g * 32 + j + 1 + t;                 // local sample index of row t
-        if (half == 0) return s_sv[li];
-        if (a.flag_mode == 2) return s_sf[li];
-        return synth_flag(a.flag_mode, k0 + g * 32 + j, t, W, cand, nullptr, 0);
-    };
-
-    // step 0: h = 0, only the input part
-    h128_xonly(accA, wx, bias_l, xin(0, 0), half, w);
-    h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
-    h128_pointwise(accA, cA, hA, fb, lane, w);
-    __syncthreads();
-    for (int t = 1; t < W; ++t) {
-        // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
-        const float bxa = xin(0, t);
-        h128_pointwise(accB, cB, hB, fb, lane, w);
-        h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
-        H128_SYNC();
-        // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
-        const float bxb = xin(1, t);
-        h128_pointwise(accA, cA, hA, fb, lane, w);
-        h128_gemm(accB, U, wx, ul, hB, bias_l, bxb, lane, half, w);
-        H128_SYNC();
-    }
-    h128_pointwise(accB, cB, hB, fb, lane, w);
     __syncthreads();
 
-    // Q head: waves 0/1 -> groups A/B; lane sums the units of its half, then the halves combine
-    if (w < 2) {
-        const float* hb = w == 0 ? hA : hB;
-        const int jw = w * 32 + j;
-        for (int act = 0; act < a.A; ++act) {
-            float part = 0.0f;
-#pragma unroll 8
-            for (int kk = 0; kk < 64; ++kk)
-                part = fmaf(hb[kk * 64 + lane], a.w_out[((kk >> 2) * 8 + 2 * (kk & 3) + half) * a.A + act], part);
-            part += __shfl_xor(part, 32);
-            if (half == 0 && jw < count)
-                a.q[((a.seg.win_off[s] + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+#if H128_ABL == 3
+        break;                                  // timing-only: the prologue alone
+#endif
+        const SegHit sg = seg_lookup(s_seg, a.seg, tile);
+        const int s = sg.s;
+        const long long samp0 = sg.samp0, nsamp = sg.nsamp, Ks = sg.Ks;
+        const long long k0 = (long long)(tile - sg.tile0) * 64;
+        const int count = (int)(Ks - k0 < 64 ? Ks - k0 : 64);
+
+        // stage the series tile (and explicit flags) into LDS, coalesced, clamped to the series
+        {
+            const bool has_norm = a.seg.in_scale != nullptr;
+            const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+            const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+            for (int i = threadIdx.x; i < 64 + W + 1 && i < H128_SV; i += 256) {
+                long long n = k0 + i;
+                if (n > nsamp - 1) n = nsamp - 1;
+                float v = a.x[samp0 + n];
+                if (has_norm) v = minmax_apply(v, sc, of);
+                s_sv[i] = v;
+                s_sf[i] = (a.flag_mode == 2) ? a.flags[samp0 + n] : 0.0f;
+            }
         }
+        __syncthreads();
+
+        f32x16 accA[4], accB[4];
+        float cA[4][4], cB[4][4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { cA[tl][qd] = 0.0f; cB[tl][qd] = 0.0f; }
+
+        // B operand of the input k-step: lanes 0-31 carry the value, lanes 32-63 the flag
+        auto xin = [&](int g, int t) -> float {
+            const int li = g * 32 + j + 1 + t;                 // local sample index of row t
+            if (half == 0) return s_sv[li];
+            if (a.flag_mode == 2) return s_sf[li];
+            return synth_flag(a.flag_mode, k0 + g * 32 + j, t, W, cand, nullptr, 0);
+        };
+
+        // step 0: h = 0, only the input part
+        h128_xonly(accA, wx, bias_l, xin(0, 0), half, w);
+        h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
+        h128_pointwise(accA, cA, hA, fb, lane, w);
+        __syncthreads();
+        for (int t = 1; t < W; ++t) {
+            // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
+            const float bxa = xin(0, t);
+            h128_pointwise(accB, cB, hB, fb, lane, w);
+            h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
+            H128_SYNC();
+            // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
+            const float bxb = xin(1, t);
+            h128_pointwise(accA, cA, hA, fb, lane, w);
+            h128_gemm(accB, U, wx, ul, hB, bias_l, bxb, lane, half, w);
+            H128_SYNC();
+        }
+        h128_pointwise(accB, cB, hB, fb, lane, w);
+        __syncthreads();
+
+        // Q head: waves 0/1 -> groups A/B; lane sums the units of its half, then the halves combine
+        if (w < 2) {
+            const float* hb = w == 0 ? hA : hB;
+            const int jw = w * 32 + j;
+            for (int act = 0; act < a.A; ++act) {
+                float part = 0.0f;
+#pragma unroll 8
+                for (int kk = 0; kk < 64; ++kk)
+                    part = fmaf(hb[kk * 64 + lane], s_wout[((kk >> 2) * 8 + 2 * (kk & 3) + half) * a.A + act], part);
+                part += __shfl_xor(part, 32);
+                if (half == 0 && jw < count)
+                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+            }
+        }
+        __syncthreads();        // h and the staged samples are rewritten by the next tile
     }
 }
 

@@ -115,99 +115,118 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_f16x3_kernel(LstmF16Args f
     __shared__ __attribute__((aligned(16))) u32x4 s_u[4][(4 - H128F_UREG) * 2 * 8 * 64 + 1];
     __shared__ float s_sv[H128_SV];
     __shared__ float s_sf[H128_SV];
+    __shared__ float s_wout[128 * 8];        // Q head, [unit][action]
+    __shared__ SegLds s_seg;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
-    const int tile = blockIdx.x;
     const int cand = blockIdx.y;
     const int W = a.W;
-    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
-    const long long samp0 = a.seg.samp_off[s];
-    const long long nsamp = a.seg.samp_off[s + 1] - samp0;
-    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
-    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 64;
-    const int count = (int)(Ks - k0 < 64 ? Ks - k0 : 64);
-    {
-        const bool has_norm = a.seg.in_scale != nullptr;
-        const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
-        const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
-        for (int i = threadIdx.x; i < 64 + W + 1 && i < H128_SV; i += 256) {
-            long long n = k0 + i;
-            if (n > nsamp - 1) n = nsamp - 1;
-            float v = a.x[samp0 + n];
-            if (has_norm) v = minmax_apply(v, sc, of);
-            s_sv[i] = v;
-            s_sf[i] = (a.flag_mode == 2) ? a.flags[samp0 + n] : 0.0f;
-        }
-        for (int i = threadIdx.x; i < 16 * 2 * 16; i += 256) s_bias[i] = a.bias[i];
-    }
+    seg_stage(s_seg, a.seg);
+    for (int i = threadIdx.x; i < 128 * a.A; i += 256) s_wout[i] = a.w_out[i];
+    // weights to registers once per workgroup; the grid is persistent (see lstm_h128i2_kernel)
     f16x8 Uhi[H128F_UREG][8], Ulo[H128F_UREG][8];
     float wx[4];
 #pragma unroll
     for (int tl = 0; tl < 4; ++tl) wx[tl] = a.wx[(4 * w + tl) * 64 + lane];
+    // all loads of a tile in flight before the first value is pinned (see lstm_h128i2_kernel)
 #pragma unroll
-    for (int tl = 0; tl < H128F_UREG; ++tl)
+    for (int tl = 0; tl < H128F_UREG; ++tl) {
+        u32x4 th[8], tlo[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            Uhi[tl][ks] = pin_agpr128(fa.uhi[((4 * w + tl) * 8 + ks) * 64 + lane]);
-            Ulo[tl][ks] = pin_agpr128(fa.ulo[((4 * w + tl) * 8 + ks) * 64 + lane]);
+            th[ks] = fa.uhi[((4 * w + tl) * 8 + ks) * 64 + lane];
+            tlo[ks] = fa.ulo[((4 * w + tl) * 8 + ks) * 64 + lane];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            Uhi[tl][ks] = pin_agpr128(th[ks]);
+            Ulo[tl][ks] = pin_agpr128(tlo[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     u32x4* ul = &s_u[w][0];
     for (int tl = H128F_UREG; tl < 4; ++tl)
+#pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             ul[(((tl - H128F_UREG) * 2 + 0) * 8 + ks) * 64 + lane] = fa.uhi[((4 * w + tl) * 8 + ks) * 64 + lane];
             ul[(((tl - H128F_UREG) * 2 + 1) * 8 + ks) * 64 + lane] = fa.ulo[((4 * w + tl) * 8 + ks) * 64 + lane];
         }
-    __syncthreads();
-
+    for (int i = threadIdx.x; i < 16 * 2 * 16; i += 256) s_bias[i] = a.bias[i];
     const float* bias_l = s_bias;
-    f32x16 accA[4], accB[4];
-    float cA[4][4], cB[4][4];
-#pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) { cA[tl][qd] = 0.0f; cB[tl][qd] = 0.0f; }
-
-    auto xin = [&](int g, int t) -> float {
-        const int li = g * 32 + j + 1 + t;
-        if (half == 0) return s_sv[li];
-        if (a.flag_mode == 2) return s_sf[li];
-        return synth_flag(a.flag_mode, k0 + g * 32 + j, t, W, cand, nullptr, 0);
-    };
-
-    h128_xonly(accA, wx, bias_l, xin(0, 0), half, w);
-    h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
-    h128f_pointwise(accA, cA, s_hiA, s_loA, half, j, w);
-    __syncthreads();
-    for (int t = 1; t < W; ++t) {
-        const float bxa = xin(0, t);
-        h128f_pointwise(accB, cB, s_hiB, s_loB, half, j, w);
-        h128f_gemm(accA, Uhi, Ulo, wx, ul, s_hiA, s_loA, bias_l, bxa, lane, half, j, w);
-        __syncthreads();
-        const float bxb = xin(1, t);
-        h128f_pointwise(accA, cA, s_hiA, s_loA, half, j, w);
-        h128f_gemm(accB, Uhi, Ulo, wx, ul, s_hiB, s_loB, bias_l, bxb, lane, half, j, w);
-        __syncthreads();
-    }
-    h128f_pointwise(accB, cB, s_hiB, s_loB, half, j, w);
     __syncthreads();
 
-    // Q head: waves 0/1 -> groups A/B; lane (half, j) sums the 64 units of gate tiles 8*half..8*half+7
-    if (w < 2) {
-        const _Float16* hh = w == 0 ? s_hiA : s_hiB;
-        const _Float16* hl = w == 0 ? s_loA : s_loB;
-        const int jw = w * 32 + j;
-        for (int act = 0; act < a.A; ++act) {
-            float part = 0.0f;
-            for (int g = 8 * half; g < 8 * half + 8; ++g)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int off = (g * 32 + j) * 8 + i;
-                    const float hv = (float)hh[off] + (float)hl[off];
-                    part = fmaf(hv, a.w_out[(8 * g + 2 * (i & 3) + (i >> 2)) * a.A + act], part);
-                }
-            part += __shfl_xor(part, 32);
-            if (half == 0 && jw < count)
-                a.q[((a.seg.win_off[s] + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const SegHit sg = seg_lookup(s_seg, a.seg, tile);
+        const int s = sg.s;
+        const long long samp0 = sg.samp0, nsamp = sg.nsamp, Ks = sg.Ks;
+        const long long k0 = (long long)(tile - sg.tile0) * 64;
+        const int count = (int)(Ks - k0 < 64 ? Ks - k0 : 64);
+        {
+            const bool has_norm = a.seg.in_scale != nullptr;
+            const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+            const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+            for (int i = threadIdx.x; i < 64 + W + 1 && i < H128_SV; i += 256) {
+                long long n = k0 + i;
+                if (n > nsamp - 1) n = nsamp - 1;
+                float v = a.x[samp0 + n];
+                if (has_norm) v = minmax_apply(v, sc, of);
+                s_sv[i] = v;
+                s_sf[i] = (a.flag_mode == 2) ? a.flags[samp0 + n] : 0.0f;
+            }
         }
+        __syncthreads();
+
+        f32x16 accA[4], accB[4];
+        float cA[4][4], cB[4][4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { cA[tl][qd] = 0.0f; cB[tl][qd] = 0.0f; }
+
+        auto xin = [&](int g, int t) -> float {
+            const int li = g * 32 + j + 1 + t;
+            if (half == 0) return s_sv[li];
+            if (a.flag_mode == 2) return s_sf[li];
+            return synth_flag(a.flag_mode, k0 + g * 32 + j, t, W, cand, nullptr, 0);
+        };
+
+        h128_xonly(accA, wx, bias_l, xin(0, 0), half, w);
+        h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
+        h128f_pointwise(accA, cA, s_hiA, s_loA, half, j, w);
+        __syncthreads();
+        for (int t = 1; t < W; ++t) {
+            const float bxa = xin(0, t);
+            h128f_pointwise(accB, cB, s_hiB, s_loB, half, j, w);
+            h128f_gemm(accA, Uhi, Ulo, wx, ul, s_hiA, s_loA, bias_l, bxa, lane, half, j, w);
+            __syncthreads();
+            const float bxb = xin(1, t);
+            h128f_pointwise(accA, cA, s_hiA, s_loA, half, j, w);
+            h128f_gemm(accB, Uhi, Ulo, wx, ul, s_hiB, s_loB, bias_l, bxb, lane, half, j, w);
+            __syncthreads();
+        }
+        h128f_pointwise(accB, cB, s_hiB, s_loB, half, j, w);
+        __syncthreads();
+
+        // Q head: waves 0/1 -> groups A/B; lane (half, j) sums the 64 units of gate tiles 8*half..8*half+7
+        if (w < 2) {
+            const _Float16* hh = w == 0 ? s_hiA : s_hiB;
+            const _Float16* hl = w == 0 ? s_loA : s_loB;
+            const int jw = w * 32 + j;
+            for (int act = 0; act < a.A; ++act) {
+                float part = 0.0f;
+                for (int g = 8 * half; g < 8 * half + 8; ++g)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int off = (g * 32 + j) * 8 + i;
+                        const float hv = (float)hh[off] + (float)hl[off];
+                        part = fmaf(hv, s_wout[(8 * g + 2 * (i & 3) + (i >> 2)) * a.A + act], part);
+                    }
+                part += __shfl_xor(part, 32);
+                if (half == 0 && jw < count)
+                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+            }
+        }
+        __syncthreads();        // h and the staged samples are rewritten by the next tile
     }
 }
