@@ -153,9 +153,11 @@ def cpu_baseline(wl):
                       f"~100x slower, BASELINE.md)"}
 
 
-def pmc_traffic(name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of the
-    same workload (profiles/rNN/<workload>_pmc_summary.json), or None."""
+def pmc_traffic(name, variant):
+    """HBM bytes per launch of the dominant kernel (the LSTM variant that ran) from the committed
+    rocprofv3 PMC summary of the same workload (profiles/rNN/<workload>_pmc_summary.json), or None."""
+    kern = {"h128i2": "lstm_h128i2_kernel", "h128i2_f16x3": "lstm_h128i2_f16x3_kernel",
+            "xproj+rec": "lstm_rec_kernel", "generic": "lstm_generic_kernel"}.get(variant, "lstm_")
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{name}_pmc_summary.json"))):
@@ -165,7 +167,7 @@ def pmc_traffic(name):
     try:
         d = json.load(open(best))
         for k, v in d["kernels"].items():
-            if k.startswith("lstm_") and "hbm_bytes_per_launch" in v:
+            if kern in k and "hbm_bytes_per_launch" in v:
                 return v["hbm_bytes_per_launch"]
     except Exception:
         return None
@@ -318,7 +320,7 @@ def main():
                        "lstm_kernel": variant},
             "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(wl["name"]),
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(wl["name"], variant),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": (4 * wl["F"] + 4 + 4 * 2 * S + 4) * K,
                          "avg_launch_ms": lstm_avg_s * 1e3, "launches": lstm_n,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box: bench of every workload, rocprofv3 kernel stats and PMC passes for C2.
+# Runs on the GPU box: bench of every workload, rocprofv3 kernel stats for C2/C4 and PMC passes for C2/C4.
 # Results land in gpurun_out/round/ ; copy what matters into profiles/rNN/.
 set -e
 out=gpurun_out/round; mkdir -p $out
@@ -10,10 +10,14 @@ for w in c1 c3 c4 c5; do
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --no-cpu-baseline > $out/trace_c2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c4 -- python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c4.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $out/pmc_sq -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_sq.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_inst -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_inst.log 2>&1
+# PMC passes, one counter group per run (a run may hold at most 8 SQ / 4 TCC counters): C2 and C4
+for w in c2 c4; do
+  args="--workload $w --steps 5 --warmup 1 --no-cpu-baseline"
+  timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $out/pmc_${w}_sq -- python bench.py $args > $out/pmc_${w}_sq.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${w}_fetch -- python bench.py $args > $out/pmc_${w}_fetch.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${w}_write -- python bench.py $args > $out/pmc_${w}_write.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_${w}_inst -- python bench.py $args > $out/pmc_${w}_inst.log 2>&1
+done
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]
