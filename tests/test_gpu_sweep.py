@@ -1,0 +1,134 @@
+"""Randomised shape sweep of the HIP path against the oracle (through the C-ABI): window lengths,
+feature counts, hidden widths, VAE depths, ragged batches with too-short series, every flag mode,
+device-side MinMax, RobustScaler/clip — the corners the named configurations do not visit.
+Same tolerance as tests/test_gpu_parity.py (1e-5 relative, fp32)."""
+import numpy as np
+import pytest
+
+from oracle import ref_path as orc
+from test_gpu_parity import RTOL, synth_lstm, synth_vae
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scorer():
+    from drlvae.scorer import WindowScorer
+    s = WindowScorer(0)
+    yield s
+    s.close()
+
+
+def _nrel(got, want):
+    """norm-wise relative error per window (rows)"""
+    got = np.asarray(got, np.float64).reshape(len(got), -1)
+    want = np.asarray(want, np.float64).reshape(len(want), -1)
+    return (np.abs(got - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-30)).max() if len(want) else 0.0
+
+
+def _rand_vae(rng, D):
+    n_enc = int(rng.integers(1, 4))
+    hid = [int(rng.choice([8, 33, 64, 100, 128])) for _ in range(n_enc)]
+    lat = int(rng.choice([3, 10, 32]))
+    dec = int(rng.choice([16, 64, 128]))
+    return synth_vae(rng, [D] + hid + [lat, dec, D], n_enc), hid, dec
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_univariate_random_shapes(scorer, seed):
+    rng = np.random.default_rng(1000 + seed)
+    Wn = int(rng.integers(2, 61))
+    H = int(rng.choice([8, 32, 64, 96, 128]))
+    A = int(rng.choice([2, 2, 3, 4]))
+    vae, _, _ = _rand_vae(rng, Wn)
+    lstm = synth_lstm(rng, 2, H, A)
+    n_seg = int(rng.integers(1, 6))
+    lens = [int(rng.integers(max(1, Wn - 3), Wn + 180)) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = Wn + int(rng.integers(1, 150))      # at least one series with windows
+    raw = [rng.normal(5.0, 3.0, n).astype(np.float32) for n in lens]
+    mode = ["zeros", "quirk", "explicit"][seed % 3]
+    device_minmax = bool(seed % 2)
+    mm = [orc.minmax_f32(r) for r in raw]                # (normalised, scale_, min_)
+    norm = [m[0] for m in mm]
+    params = [(m[1], m[2]) for m in mm]
+    flags = [(rng.random(n) < 0.3).astype(np.float32) for n in lens]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    kw = dict(flag_mode=mode)
+    if mode == "explicit":
+        kw["flags"] = np.concatenate(flags)
+    if device_minmax:
+        kw["in_scale"] = np.array([p[0] for p in params], np.float32)
+        kw["in_offset"] = np.array([p[1] for p in params], np.float32)
+        out = scorer.score(np.concatenate(raw), Wn, off, **kw)
+    else:
+        out = scorer.score(np.concatenate(norm), Wn, off, **kw)
+    K = int(sum(max(0, n - Wn) for n in lens))
+    assert out["err"].shape == (K,) and out["q"].shape == (K, A) and out["action"].shape == (K,)
+    pos = 0
+    for v, fl, n in zip(norm, flags, lens):
+        k = max(0, n - Wn)
+        if k == 0:
+            continue
+        X = orc.vae_windows_univariate(v, Wn)
+        rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
+                              10.0, dtype=np.float64)
+        err = orc.recon_error(X, rec, dtype=np.float64)
+        S = orc.states_list_univariate(v, Wn)
+        if mode == "zeros":
+            S[:, :, 1] = 0
+        elif mode == "explicit":
+            # flag of row t of window k = per-sample flag of that row's sample (k+1+t)
+            idx = np.arange(k)[:, None] + 1 + np.arange(Wn)[None, :]
+            S[:, :, 1] = fl[idx]
+        q = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float64)
+        np.testing.assert_allclose(out["err"][pos:pos + k], err, rtol=RTOL, err_msg=f"W={Wn} H={H}")
+        assert _nrel(out["q"][pos:pos + k], q) <= RTOL, (Wn, H, A, mode, device_minmax, scorer.lstm_variant)
+        srt = np.sort(q, axis=1)
+        safe = (srt[:, -1] - srt[:, -2]) > 4 * RTOL * np.abs(q).max(axis=1)
+        assert np.array_equal(out["action"][pos:pos + k][safe], np.argmax(q, axis=1)[safe])
+        np.testing.assert_array_equal(out["margin"][pos:pos + k],
+                                      np.abs(out["q"][pos:pos + k, 0] - out["q"][pos:pos + k, 1]))
+        pos += k
+    assert pos == K
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_multivariate_random_shapes(scorer, seed):
+    rng = np.random.default_rng(2000 + seed)
+    Wn = int(rng.integers(3, 31))
+    F = int(rng.choice([2, 5, 17, 40]))
+    H = int(rng.choice([16, 40, 64, 104, 128]))
+    D = Wn * F
+    vae, hid, dec = _rand_vae(rng, D)
+    lstm = synth_lstm(rng, F + 1, H)
+    n_seg = int(rng.integers(1, 4))
+    lens = [int(rng.integers(max(1, Wn - 2), Wn + 120)) for _ in range(n_seg)]
+    lens[0] = Wn + int(rng.integers(1, 120))
+    xs = [rng.random((n, F), dtype=np.float32) for n in lens]
+    scaled = bool(seed % 2)
+    center = rng.uniform(0.3, 0.7, D).astype(np.float32) if scaled else None
+    scale = rng.uniform(0.05, 0.6, D).astype(np.float32) if scaled else None
+    clip = 2.0 if scaled else 0.0                       # tight enough to actually clip
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    out = scorer.score(np.concatenate(xs), Wn, off, vae_lag=0, flag_mode="both", action_rule="wadi",
+                       vae_center=center, vae_scale=scale, vae_clip=clip)
+    K = int(sum(max(0, n - Wn) for n in lens))
+    assert out["q"].shape == (K, 2, 2)
+    pos = 0
+    for x, n in zip(xs, lens):
+        k = max(0, n - Wn)
+        if k == 0:
+            continue
+        want = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float64)
+        np.testing.assert_allclose(out["err"][pos:pos + k], want["err"], rtol=RTOL,
+                                   err_msg=f"W={Wn} F={F} hid={hid} dec={dec} {scorer._lib.drl_last_lstm_variant(scorer._h)}")
+        assert _nrel(out["q"][pos:pos + k], want["q"]) <= RTOL, (Wn, F, H, scorer.lstm_variant)
+        m = np.abs(want["q"][:, 1, 1] - want["q"][:, 0, 0])
+        safe = m > 4 * RTOL * np.abs(want["q"]).max(axis=(1, 2))
+        assert np.array_equal(out["action"][pos:pos + k][safe], want["action"][safe])
+        pos += k
+    assert pos == K
