@@ -42,3 +42,16 @@ def test_create_without_gpu_fails_loudly():
     from drlvae.scorer import WindowScorer
     with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device|failed"):
         WindowScorer(0)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/drlvae.h is the boundary a C host binds: it must compile as C, not only as C++."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "drlvae.h"\nint main(void) { drl_score_opts o; o.struct_size = (int)sizeof o; '
+                   'return o.struct_size == 72 ? 0 : 1; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    exe = tmp_path / "use"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{inc}", str(src), "-o", str(exe),
+                    "-Wl,--unresolved-symbols=ignore-all"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0          # struct layout = what _abi.ScoreOpts declares
