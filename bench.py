@@ -263,6 +263,7 @@ def main():
     vae_ms, vae_n = sc.profile_read(1)
     sc.profile(False)
     variant = sc.lstm_variant  # of the headline run (the alt run below changes it)
+    overlapped = sc.overlapped
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,7 +318,8 @@ def main():
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
                        "collective": ("none" if gathered is None else "gloo all_gather (REHEARSAL, not a measurement)"
                                       if rehearse else "one rccl all_gather of the packed err/q/action/margin block per step"),
-                       "lstm_kernel": variant},
+                       "lstm_kernel": variant,
+                       "vae_and_lstm_kernels_overlap": overlapped},
             "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(wl["name"], variant),

@@ -61,6 +61,13 @@ struct drl_ctx {
     int n_cu = 256;               // compute units: size of the persistent grids
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // the VAE kernel and the LSTM kernels of one scoring call are independent: the VAE is launched on a
+    // second stream (forked from / joined back into `stream` with events) and fills the CUs the LSTM
+    // grid leaves idle in its last round
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
+    bool last_overlap = false;
     std::string err;
     VaeHost vae;
     LstmHost lstm;
@@ -153,7 +160,7 @@ void pack_bias(const float* b, int dout, float* dst, double scale) {
             }
 }
 
-void prof_begin(drl_ctx* c, int which) {
+void prof_begin(drl_ctx* c, int which, hipStream_t st) {
     if (!c->prof.on) return;
     Prof::Pair p;
     for (hipEvent_t* e : {&p.a, &p.b}) {
@@ -161,13 +168,13 @@ void prof_begin(drl_ctx* c, int which) {
         else if (hipEventCreate(e) != hipSuccess) { *e = nullptr; }
     }
     p.which = which;
-    if (p.a) (void)hipEventRecord(p.a, c->stream);
+    if (p.a) (void)hipEventRecord(p.a, st);
     c->prof.pending.push_back(p);
 }
-void prof_end(drl_ctx* c) {
+void prof_end(drl_ctx* c, hipStream_t st) {
     if (!c->prof.on || c->prof.pending.empty()) return;
     Prof::Pair& p = c->prof.pending.back();
-    if (p.b) (void)hipEventRecord(p.b, c->stream);
+    if (p.b) (void)hipEventRecord(p.b, st);
 }
 int prof_collect(drl_ctx* c) {
     for (auto& p : c->prof.pending) {
@@ -313,6 +320,14 @@ int drl_create(int device_id, drl_ctx** out) {
         return fail(nullptr, DRL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        c->overlap_mode = 0;                    // degrade to one stream, never fail creation for it
+        c->aux_stream = nullptr;
+    }
+    if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
     *out = c;
     return DRL_OK;
 }
@@ -327,6 +342,9 @@ void drl_destroy(drl_ctx* c) {
                       &c->st_err, &c->st_q, &c->st_act, &c->st_margin})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -618,7 +636,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
     seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t32;
     seg.in_scale = od.in_scale; seg.in_offset = od.in_offset; seg.n_seg = n_seg; seg.W = W;
 
-    if (want_vae) {
+    auto launch_vae = [&](hipStream_t vst) -> int {
         VaeArgs a;
         memset(&a, 0, sizeof a);
         fill_vae_args(c, a);
@@ -631,7 +649,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         const bool wide = W * F > 128 && !d_eps && wide_lds <= 160 * 1024 &&
                           c->vae.dout[0] > 96 && c->vae.dout[0] <= 128 &&
                           c->vae.din[c->vae.n_path - 1] > 96 && c->vae.din[c->vae.n_path - 1] <= 128;
-        prof_begin(c, 1);
+        prof_begin(c, 1, vst);
         if (wide) {
             if (wide_lds > c->wide_lds_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide_kernel<true>),
@@ -641,15 +659,27 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 c->wide_lds_set = 160 * 1024;
             }
             const dim3 grid((sh.tiles32 + 3) / 4);
-            if (a.center) hipLaunchKernelGGL(vae_wide_kernel<true>, grid, dim3(256), wide_lds, c->stream, a, xr_floats);
-            else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, c->stream, a, xr_floats);
+            if (a.center) hipLaunchKernelGGL(vae_wide_kernel<true>, grid, dim3(256), wide_lds, vst, a, xr_floats);
+            else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, vst, a, xr_floats);
             c->last_vae_variant = "wide";
         } else {
-            hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, vst, a);
             c->last_vae_variant = "chain";
         }
-        prof_end(c);
+        prof_end(c, vst);
         HIP_TRY(c, hipGetLastError());
+        return DRL_OK;
+    };
+    // Worth it only when the VAE is a real GEMM (wide windows) and the call is large: measured +7 % on C4
+    // (172,776 windows, D = 3075), +1 % on C2, -2 % on C3 (28,454 windows: the fork/join costs more than
+    // the tail it fills).  DRLVAE_OVERLAP=0 turns it off, =2 forces it for every call.
+    const bool big_wide = W * F > 128 && sh.K_total >= 65536;
+    const bool overlap = want_vae && want_q && c->aux_stream && (c->overlap_mode == 2 || (c->overlap_mode == 1 && big_wide));
+    c->last_overlap = overlap;
+    if (want_vae && !overlap && (rc = launch_vae(c->stream))) return rc;
+    if (overlap) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
     }
     if (want_q) {
         LstmArgs a;
@@ -660,7 +690,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
         a.q = d_q;
         const bool fast = c->lstm.I == 2 && c->lstm.H == 128 && F == 1 && W >= 2 && W + 65 <= H128_SV;
-        prof_begin(c, 0);
+        prof_begin(c, 0, c->stream);
         if (fast && c->lstm_math == 1 && c->lstm.has_split) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             LstmF16Args fa;
@@ -708,8 +738,14 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
             c->last_variant = "generic";
         }
-        prof_end(c);
+        prof_end(c, c->stream);
         HIP_TRY(c, hipGetLastError());
+        if (overlap) {
+            // the LSTM grid is already queued (it is the long one and takes the CUs first)
+            if ((rc = launch_vae(c->aux_stream))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
         if (d_action || d_margin) {
             const int bs = 256;
             hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((sh.K_total + bs - 1) / bs)), dim3(bs), 0, c->stream,
@@ -833,9 +869,9 @@ int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, flo
     a.n_tiles = sh.tiles32;
     a.err = (float*)c->st_err.p;
     a.recon = recon ? (float*)c->st_q.p : nullptr;
-    prof_begin(c, 1);
+    prof_begin(c, 1, c->stream);
     hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
-    prof_end(c);
+    prof_end(c, c->stream);
     HIP_TRY(c, hipGetLastError());
     if (recon) HIP_TRY(c, hipMemcpyAsync(recon, c->st_q.p, nb, hipMemcpyDeviceToHost, c->stream));
     if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -867,10 +903,10 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     a.n_tiles = sh.tiles32; a.S = 1; a.q = (float*)c->st_q.p;
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
-    prof_begin(c, 0);
+    prof_begin(c, 0, c->stream);
     if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
-    prof_end(c);
+    prof_end(c, c->stream);
     c->last_variant = "generic";
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1028,5 +1064,6 @@ int drl_profile_read(drl_ctx* c, int which, double* total_ms, int64_t* launches)
     return DRL_OK;
 }
 const char* drl_last_lstm_variant(drl_ctx* c) { return c ? c->last_variant : "none"; }
+int drl_last_call_overlapped(drl_ctx* c) { return c && c->last_overlap ? 1 : 0; }
 
 }  // extern "C"

@@ -274,3 +274,8 @@ class WindowScorer:
     @property
     def lstm_variant(self) -> str:
         return self._lib.drl_last_lstm_variant(self._h).decode()
+
+    @property
+    def overlapped(self) -> bool:
+        """True when the last scoring call ran its VAE kernel concurrently with the LSTM kernels."""
+        return bool(self._lib.drl_last_call_overlapped(self._h))

@@ -199,6 +199,11 @@ int drl_profile_reset(drl_ctx* ctx);
 int drl_profile_read(drl_ctx* ctx, int which, double* total_ms, int64_t* launches);
 /* Name of the LSTM kernel variant the last scoring call used ("h128i2" or "generic"). */
 const char* drl_last_lstm_variant(drl_ctx* ctx);
+/* 1 when the last scoring call ran its VAE kernel on the library's second stream, concurrently with
+ * the LSTM kernels (large wide-window calls; environment DRLVAE_OVERLAP = 0 never, 1 default,
+ * 2 always).  Kernel durations read with drl_profile_read then overlap in time.  No counterpart in
+ * the reference. */
+int drl_last_call_overlapped(drl_ctx* ctx);
 
 #ifdef __cplusplus
 }
