@@ -34,6 +34,7 @@ struct VaeHost {
     float lv_clip = 0;
     int latent = 0;
     int D = 0;                            // input width
+    bool narrow = false;                  // every hidden width <= 64: vae_kernel<2>
 };
 
 struct LstmHost {
@@ -410,6 +411,8 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
         v.b_off[p] = off; off += up16(nout * 32);
     }
     v.D = v.din[0];
+    v.narrow = true;
+    for (int p = 0; p + 1 < v.n_path; ++p) v.narrow = v.narrow && v.dout[p] <= 64;
     if (v.dout[v.n_path - 1] != v.D)
         return fail(c, DRL_ERR_ARG, "drl_set_vae: output width %d != input width %d", v.dout[v.n_path - 1], v.D);
     v.latent = out_dims[mu_layer];
@@ -663,7 +666,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, vst, a, xr_floats);
             c->last_vae_variant = "wide";
         } else {
-            hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, vst, a);
+            if (c->vae.narrow) hipLaunchKernelGGL(vae_kernel<2>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, vst, a);
+            else hipLaunchKernelGGL(vae_kernel<DRL_VAE_MAX_TILES>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, vst, a);
             c->last_vae_variant = "chain";
         }
         prof_end(c, vst);
@@ -870,7 +874,8 @@ int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, flo
     a.err = (float*)c->st_err.p;
     a.recon = recon ? (float*)c->st_q.p : nullptr;
     prof_begin(c, 1, c->stream);
-    hipLaunchKernelGGL(vae_kernel, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+    if (c->vae.narrow) hipLaunchKernelGGL(vae_kernel<2>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(vae_kernel<DRL_VAE_MAX_TILES>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
     prof_end(c, c->stream);
     HIP_TRY(c, hipGetLastError());
     if (recon) HIP_TRY(c, hipMemcpyAsync(recon, c->st_q.p, nb, hipMemcpyDeviceToHost, c->stream));

@@ -181,7 +181,11 @@ __device__ __forceinline__ float vae_input(const VaeArgs& a, const float* __rest
     return v;
 }
 
-__global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
+// MAXT = accumulator tiles kept per layer: 2 when every hidden width is <= 64 (the univariate
+// VAEs), else MAXT.  The kernel is latency-bound (weights come from L2 per MFMA, 256
+// MFMAs per 32 windows), so the narrow instantiation's lower register count buys resident waves.
+template <int MAXT>
+__global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
     const int tile = blockIdx.x * 4 + wave;
@@ -200,27 +204,27 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
     const float* __restrict__ xin = a.x + samp0 * a.win_stride + a.lag_elems + (k0 + jj) * a.win_stride;
     const long long wout = a.seg.win_off[s] + k0 + jj;
 
-    f32x16 cur[DRL_VAE_MAX_TILES], nxt[DRL_VAE_MAX_TILES];
+    f32x16 cur[MAXT], nxt[MAXT];
 
     // ---- layer 0: input from memory
     {
         const int nin = (a.din[0] + 31) >> 5, nout = (a.dout[0] + 31) >> 5;
         const float* __restrict__ w = a.w[0];
 #pragma unroll
-        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+        for (int ot = 0; ot < MAXT; ++ot)
             cur[ot] = ot < nout ? load_bias16(a.b[0], ot, half) : f32x16{};
         for (int it = 0; it < nin; ++it) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float bv = vae_input(a, xin, it * 32 + rowmap(r, half), has_norm, sc, of);
 #pragma unroll
-                for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+                for (int ot = 0; ot < MAXT; ++ot)
                     if (ot < nout)
                         cur[ot] = mfma32(w[(((size_t)it * nout + ot) * 16 + r) * 64 + lane], bv, cur[ot]);
             }
         }
 #pragma unroll
-        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot) act16(cur[ot], a.act[0]);
+        for (int ot = 0; ot < MAXT; ++ot) act16(cur[ot], a.act[0]);
     }
 
     // ---- middle layers: registers -> registers
@@ -230,16 +234,16 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
         const bool with_lv = (p == a.mu_idx) && a.eps != nullptr;
         f32x16 lv = {};
 #pragma unroll
-        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+        for (int ot = 0; ot < MAXT; ++ot)
             nxt[ot] = ot < nout ? load_bias16(a.b[p], ot, half) : f32x16{};
         if (with_lv) lv = load_bias16(a.b_lv, 0, half);
 #pragma unroll
-        for (int it = 0; it < DRL_VAE_MAX_TILES; ++it) {
+        for (int it = 0; it < MAXT; ++it) {
             if (it < nin) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
 #pragma unroll
-                    for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot)
+                    for (int ot = 0; ot < MAXT; ++ot)
                         if (ot < nout)
                             nxt[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], nxt[ot]);
                     if (with_lv)   // latent <= 32: one output tile
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
             }
         }
 #pragma unroll
-        for (int ot = 0; ot < DRL_VAE_MAX_TILES; ++ot) { cur[ot] = nxt[ot]; act16(cur[ot], a.act[p]); }
+        for (int ot = 0; ot < MAXT; ++ot) { cur[ot] = nxt[ot]; act16(cur[ot], a.act[p]); }
         if (with_lv) {
             // z = mu + exp(0.5*clip(logvar))*eps   (reference myasp-A1.py:84, 94)
 #pragma unroll
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void vae_kernel(VaeArgs a) {
         for (int ot = 0; ot < nout; ++ot) {
             f32x16 acc = load_bias16(a.b[p], ot, half);
 #pragma unroll
-            for (int it = 0; it < DRL_VAE_MAX_TILES; ++it) {
+            for (int it = 0; it < MAXT; ++it) {
                 if (it < nin) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
