@@ -703,10 +703,15 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.ulo = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.ulo_off);
             hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
             c->last_variant = "h128i2_f16x3";
+        } else if (fast && sh.tiles32 <= c->n_cu) {
+            // a small call (one series, a replay batch): 32-window tiles over twice as many CUs
+            a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
+            hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, a);
+            c->last_variant = "h128i2";
         } else if (fast) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
-            hipLaunchKernelGGL(lstm_h128i2_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
+            hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
         } else if (c->lstm.NT == 8 && !od.in_scale &&
                    (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)64 << 30)) {   // projections: 1 KiB per sample (a chunk stays < 4 GiB)

@@ -930,6 +930,10 @@ __device__ __forceinline__ void h128_pointwise(const f32x16 (&acc)[4], float (&c
 #define H128_SYNC() __syncthreads()
 #endif
 
+// NG = window groups of 32 per tile.  2 is the throughput shape (64 windows per tile).  1 halves the
+// tile so that a call with no more 32-window tiles than CUs (one Yahoo series, a replay batch) spreads
+// over twice as many CUs: same arithmetic per window, half the latency.
+template <int NG>
 __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
     // separate objects so that alias analysis can tell group A's h from group B's
     __shared__ __attribute__((aligned(16))) float s_hA[64 * 64];   // [k-step][lane]
@@ -985,15 +989,15 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
         const SegHit sg = seg_lookup(s_seg, a.seg, tile);
         const int s = sg.s;
         const long long samp0 = sg.samp0, nsamp = sg.nsamp, Ks = sg.Ks;
-        const long long k0 = (long long)(tile - sg.tile0) * 64;
-        const int count = (int)(Ks - k0 < 64 ? Ks - k0 : 64);
+        const long long k0 = (long long)(tile - sg.tile0) * (32 * NG);
+        const int count = (int)(Ks - k0 < 32 * NG ? Ks - k0 : 32 * NG);
 
         // stage the series tile (and explicit flags) into LDS, coalesced, clamped to the series
         {
             const bool has_norm = a.seg.in_scale != nullptr;
             const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
             const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
-            for (int i = threadIdx.x; i < 64 + W + 1 && i < H128_SV; i += 256) {
+            for (int i = threadIdx.x; i < 32 * NG + W + 1 && i < H128_SV; i += 256) {
                 long long n = k0 + i;
                 if (n > nsamp - 1) n = nsamp - 1;
                 float v = a.x[samp0 + n];
@@ -1021,26 +1025,34 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
 
         // step 0: h = 0, only the input part
         h128_xonly(accA, wx, bias_l, xin(0, 0), half, w);
-        h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
+        if (NG == 2) h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
         h128_pointwise(accA, cA, hA, fb, lane, w);
         __syncthreads();
         for (int t = 1; t < W; ++t) {
-            // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
-            const float bxa = xin(0, t);
-            h128_pointwise(accB, cB, hB, fb, lane, w);
-            h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
-            H128_SYNC();
-            // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
-            const float bxb = xin(1, t);
-            h128_pointwise(accA, cA, hA, fb, lane, w);
-            h128_gemm(accB, U, wx, ul, hB, bias_l, bxb, lane, half, w);
-            H128_SYNC();
+            if (NG == 2) {
+                // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
+                const float bxa = xin(0, t);
+                h128_pointwise(accB, cB, hB, fb, lane, w);
+                h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
+                H128_SYNC();
+                // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
+                const float bxb = xin(1, t);
+                h128_pointwise(accA, cA, hA, fb, lane, w);
+                h128_gemm(accB, U, wx, ul, hB, bias_l, bxb, lane, half, w);
+                H128_SYNC();
+            } else {
+                const float bxa = xin(0, t);
+                h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
+                H128_SYNC();                    // every wave has read h_{t-1}
+                h128_pointwise(accA, cA, hA, fb, lane, w);
+                H128_SYNC();                    // h_t is complete
+            }
         }
-        h128_pointwise(accB, cB, hB, fb, lane, w);
+        if (NG == 2) h128_pointwise(accB, cB, hB, fb, lane, w);
         __syncthreads();
 
         // Q head: waves 0/1 -> groups A/B; lane sums the units of its half, then the halves combine
-        if (w < 2) {
+        if (w < NG) {
             const float* hb = w == 0 ? hA : hB;
             const int jw = w * 32 + j;
             for (int act = 0; act < a.A; ++act) {

@@ -298,6 +298,25 @@ def test_shards_are_bit_identical_to_the_whole(scorer, a1, ckpt_a1):
             assert np.array_equal(got.view(np.uint32), whole[k].view(np.uint32)), (world, k)
 
 
+def test_small_calls_match_large_calls_bit_for_bit(scorer, a1, ckpt_a1):
+    """A call with few windows runs the univariate LSTM on 32-window tiles, a large one on 64-window
+    tiles (persistent grid): the same series must score identically, bit for bit, either way."""
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    series = a1["series"]
+    off = np.concatenate([[0], np.cumsum([len(v) for v in series])]).astype(np.int64)
+    big = scorer.score(np.concatenate(series), W, off, flag_mode="quirk")          # 93,191 windows
+    pos = 0
+    for i, v in enumerate(series):
+        k = len(v) - W
+        if i in (0, 7, 31, 66):
+            one = scorer.score(v, W, flag_mode="quirk")                             # ~1,400 windows
+            for key in big:
+                assert np.array_equal(one[key].view(np.uint32), big[key][pos:pos + k].view(np.uint32)), (i, key)
+        pos += k
+
+
 def test_reference_call_surface_shims(scorer, a1, ckpt_a1):
     from drlvae import compat
     lstm, vae = ckpt_a1
