@@ -674,11 +674,14 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         HIP_TRY(c, hipGetLastError());
         return DRL_OK;
     };
-    // Worth it only when the VAE is a real GEMM (wide windows) and the call is large: measured +7 % on C4
+    // Worth it when the VAE is a real GEMM (wide windows) and the call is large — measured +7 % on C4
     // (172,776 windows, D = 3075), +1 % on C2, -2 % on C3 (28,454 windows: the fork/join costs more than
-    // the tail it fills).  DRLVAE_OVERLAP=0 turns it off, =2 forces it for every call.
+    // the tail it fills) — and when the call is so small that the LSTM grid leaves CUs idle anyway
+    // (C1, 1,395 windows: +13 %).  DRLVAE_OVERLAP=0 turns it off, =2 forces it for every call.
     const bool big_wide = W * F > 128 && sh.K_total >= 65536;
-    const bool overlap = want_vae && want_q && c->aux_stream && (c->overlap_mode == 2 || (c->overlap_mode == 1 && big_wide));
+    const bool small = (long long)sh.tiles32 * (o->flag_mode == DRL_FLAG_BOTH ? 2 : 1) <= (long long)c->n_cu * 3 / 4;
+    const bool overlap = want_vae && want_q && c->aux_stream &&
+                         (c->overlap_mode == 2 || (c->overlap_mode == 1 && (big_wide || small)));
     c->last_overlap = overlap;
     if (want_vae && !overlap && (rc = launch_vae(c->stream))) return rc;
     if (overlap) {
