@@ -917,10 +917,21 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
     prof_begin(c, 0, c->stream);
-    if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
+    if (I == 2 && c->lstm.H == 128 && W >= 2) {
+        // the register-stationary univariate kernel, reading the states row by row
+        if (sh.tiles32 <= c->n_cu) {
+            hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, 1), dim3(256), 0, c->stream, a);
+        } else {
+            a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+            hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), 1), dim3(256), 0, c->stream, a);
+        }
+        c->last_variant = "h128i2";
+    } else {
+        if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
+        c->last_variant = "generic";
+    }
     prof_end(c, c->stream);
-    c->last_variant = "generic";
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -993,7 +993,8 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
         const int count = (int)(Ks - k0 < 32 * NG ? Ks - k0 : 32 * NG);
 
         // stage the series tile (and explicit flags) into LDS, coalesced, clamped to the series
-        {
+        // (explicit states, flag_mode < 0, are read row by row instead: see xin)
+        if (a.flag_mode >= 0) {
             const bool has_norm = a.seg.in_scale != nullptr;
             const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
             const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
@@ -1017,6 +1018,13 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
 
         // B operand of the input k-step: lanes 0-31 carry the value, lanes 32-63 the flag
         auto xin = [&](int g, int t) -> float {
+            if (a.flag_mode < 0) {
+                // explicit states [B, W, 2] (estimator.predict batches): row t of this lane's state,
+                // requested one step ahead of its use by the loop below
+                int jw = g * 32 + j;
+                if (jw > count - 1) jw = count - 1;
+                return a.x[(samp0 + k0 + jw) * a.win_stride + (long long)t * a.row_stride + half];
+            }
             const int li = g * 32 + j + 1 + t;                 // local sample index of row t
             if (half == 0) return s_sv[li];
             if (a.flag_mode == 2) return s_sf[li];
@@ -1028,20 +1036,26 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
         if (NG == 2) h128_xonly(accB, wx, bias_l, xin(1, 0), half, w);
         h128_pointwise(accA, cA, hA, fb, lane, w);
         __syncthreads();
+        // the input row of step t+1 is read while step t computes (a global load for explicit states)
+        float nxa = xin(0, W > 1 ? 1 : 0), nxb = NG == 2 ? xin(1, W > 1 ? 1 : 0) : 0.0f;
         for (int t = 1; t < W; ++t) {
+            const int tn = t + 1 < W ? t + 1 : t;
             if (NG == 2) {
                 // phase 1: MFMAs of group A step t  ||  non-linearities of group B step t-1
-                const float bxa = xin(0, t);
+                const float bxa = nxa;
+                nxa = xin(0, tn);
                 h128_pointwise(accB, cB, hB, fb, lane, w);
                 h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
                 H128_SYNC();
                 // phase 2: MFMAs of group B step t  ||  non-linearities of group A step t
-                const float bxb = xin(1, t);
+                const float bxb = nxb;
+                nxb = xin(1, tn);
                 h128_pointwise(accA, cA, hA, fb, lane, w);
                 h128_gemm(accB, U, wx, ul, hB, bias_l, bxb, lane, half, w);
                 H128_SYNC();
             } else {
-                const float bxa = xin(0, t);
+                const float bxa = nxa;
+                nxa = xin(0, tn);
                 h128_gemm(accA, U, wx, ul, hA, bias_l, bxa, lane, half, w);
                 H128_SYNC();                    // every wave has read h_{t-1}
                 h128_pointwise(accA, cA, hA, fb, lane, w);

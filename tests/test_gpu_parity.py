@@ -198,10 +198,30 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     v = a1["series"][3]
     S = orc.states_list_univariate(v, W)[:300]
     q = scorer.q_predict(S)
-    assert scorer.lstm_variant == "generic"
+    assert scorer.lstm_variant == "h128i2"              # explicit states through the register-stationary kernel
     assert_q_close(q, orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
     one = scorer.q_predict(S[:1])                       # the reference's batch-1 call pattern
     assert np.array_equal(one, q[:1])
+    # the same states scored as sliding windows of the series give the same bits
+    slid = scorer.score(v, W, flag_mode="quirk", want=("q",))["q"][:300]
+    assert np.array_equal(slid.view(np.uint32), q.view(np.uint32))
+    # a replay-sized and a large batch (64-window tiles, persistent grid) with arbitrary rows and flags
+    rng = np.random.default_rng(11)
+    big = rng.random((8192 + 700, W, 2), dtype=np.float32)
+    big[:, :, 1] = (big[:, :, 1] < 0.3)
+    qb = scorer.q_predict(big)
+    head = scorer.q_predict(big[:512])                  # 2 x 256 next-states of a DQN update
+    assert np.array_equal(head.view(np.uint32), qb[:512].view(np.uint32))
+    tail = scorer.q_predict(big[-700:])
+    assert np.array_equal(tail.view(np.uint32), qb[-700:].view(np.uint32))
+    assert_q_close(head, orc.lstm_q(big[:512], lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
+    # other shapes keep the generic kernel
+    lstm64 = synth_lstm(rng, 2, 64)
+    scorer.set_lstm(lstm64)
+    q64 = scorer.q_predict(S[:64])
+    assert scorer.lstm_variant == "generic"
+    assert_q_close(q64, orc.lstm_q(S[:64], lstm64["kernel"], lstm64["bias"], lstm64["w_out"], lstm64["b_out"], dtype=np.float64))
+    scorer.set_lstm(lstm)
     X = orc.vae_windows_univariate(v, W)[:100]
     rec, err = scorer.vae_predict(X, return_err=True)
     want = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
