@@ -185,6 +185,9 @@ def main():
                     help="recurrent product of the univariate H=128 LSTM: exact fp32 MFMA or 3-term f16 split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--collective", default="torch", choices=["torch", "abi"],
+                    help="the all-gather of the scores: torch.distributed (RCCL) or the library's own RCCL "
+                         "entry point drl_allgather_scores on the scoring stream")
     args = ap.parse_args()
 
     import torch
@@ -236,9 +239,17 @@ def main():
             gathered = torch.empty(world * words, dtype=torch.float32, device=cdev)
     stream.synchronize()
 
+    use_abi = gathered is not None and args.collective == "abi" and not rehearse
+    if use_abi:
+        ids = [sc.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        sc.comm_init(rank, world, ids[0])
+
     def step():
         sc.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
-        if gathered is not None:
+        if use_abi:
+            sc.allgather(pack, gathered)                 # RCCL on the scoring stream, no torch in between
+        elif gathered is not None:
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered, pack.cpu() if rehearse else pack)
 
@@ -317,7 +328,8 @@ def main():
                        "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
                        "collective": ("none" if gathered is None else "gloo all_gather (REHEARSAL, not a measurement)"
-                                      if rehearse else "one rccl all_gather of the packed err/q/action/margin block per step"),
+                                      if rehearse else ("one rccl all_gather (drl_allgather_scores) of the packed err/q/action/margin block per step"
+                                                       if use_abi else "one rccl all_gather of the packed err/q/action/margin block per step")),
                        "lstm_kernel": variant,
                        "vae_and_lstm_kernels_overlap": overlapped},
             "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,

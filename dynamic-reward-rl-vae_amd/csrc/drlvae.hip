@@ -5,6 +5,8 @@
 #include "lstm_f16x3.hip.h"
 
 #include <hipcub/hipcub.hpp>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -67,6 +69,10 @@ struct drl_ctx {
     // grid leaves idle in its last round
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // RCCL, loaded on first use (dlopen): the library itself has no link-time dependency on it
+    void* rccl_lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
     int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
     bool last_overlap = false;
     std::string err;
@@ -337,6 +343,7 @@ void drl_destroy(drl_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)drl_comm_destroy(c);
     for (auto& p : c->prof.pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->pbuf, &c->al_keys, &c->al_keys2, &c->al_idx, &c->al_idx2, &c->al_tmp, &c->al_sel, &c->st_in, &c->st_flags, &c->st_eps,
@@ -1089,5 +1096,83 @@ int drl_profile_read(drl_ctx* c, int which, double* total_ms, int64_t* launches)
 }
 const char* drl_last_lstm_variant(drl_ctx* c) { return c ? c->last_variant : "none"; }
 int drl_last_call_overlapped(drl_ctx* c) { return c && c->last_overlap ? 1 : 0; }
+
+/* ---- the path's only collective ------------------------------------------------------------------ */
+namespace {
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load(drl_ctx* c) {
+    if (g_rccl.AllGather) return DRL_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);      // the copy already in the process, if any
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(c, DRL_ERR_HIP, "RCCL is not loadable: %s", dlerror());
+    c->rccl_lib = h;
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.GetErrorString) {
+        g_rccl = Rccl();
+        return fail(c, DRL_ERR_HIP, "RCCL lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather/ncclCommDestroy");
+    }
+    return DRL_OK;
+}
+#define RCCL_TRY(c, expr)                                                                          \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail((c), DRL_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+}  // namespace
+
+int drl_comm_unique_id(drl_ctx* c, void* id_out) {
+    if (!c || !id_out) return DRL_ERR_ARG;
+    static_assert(DRL_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "include/drlvae.h: DRL_COMM_ID_BYTES");
+    int rc = rccl_load(c);
+    if (rc) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(c, g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return DRL_OK;
+}
+
+int drl_comm_init(drl_ctx* c, int rank, int nranks, const void* id_in) {
+    if (!c || !id_in || nranks < 1 || rank < 0 || rank >= nranks) return c ? fail(c, DRL_ERR_ARG, "drl_comm_init: bad rank/nranks/id") : DRL_ERR_ARG;
+    if (c->comm) return fail(c, DRL_ERR_STATE, "drl_comm_init: this context already has a communicator");
+    int rc = rccl_load(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    RCCL_TRY(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->comm_rank = rank; c->comm_size = nranks;
+    return DRL_OK;
+}
+
+int drl_allgather_scores(drl_ctx* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank) {
+    if (!c) return DRL_ERR_ARG;
+    if (!c->comm) return fail(c, DRL_ERR_STATE, "drl_allgather_scores: drl_comm_init was not called");
+    if (!send_dev || !recv_dev || bytes_per_rank < 0) return fail(c, DRL_ERR_ARG, "drl_allgather_scores: bad arguments");
+    if (bytes_per_rank == 0) return DRL_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    RCCL_TRY(c, g_rccl.AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, ncclInt8, c->comm, c->stream));
+    return DRL_OK;
+}
+
+int drl_comm_destroy(drl_ctx* c) {
+    if (!c) return DRL_ERR_ARG;
+    if (!c->comm) return DRL_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    RCCL_TRY(c, g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_size = 0;
+    return DRL_OK;
+}
 
 }  // extern "C"

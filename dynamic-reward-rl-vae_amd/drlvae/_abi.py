@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("DRLVAE_LIB") or os.path.join(_HERE, "libdrlvae.so")
 
 FLAG_ZEROS, FLAG_QUIRK, FLAG_EXPLICIT, FLAG_BOTH = 0, 1, 2, 3
 ACTION_ARGMAX, ACTION_WADI = 0, 1
+COMM_ID_BYTES = 128
 
 # every symbol include/drlvae.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -18,6 +19,7 @@ SYMBOLS = [
     "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
     "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
     "drl_last_lstm_variant", "drl_last_call_overlapped",
+    "drl_comm_unique_id", "drl_comm_init", "drl_allgather_scores", "drl_comm_destroy",
 ]
 
 _f32p = C.POINTER(C.c_float)
@@ -106,5 +108,9 @@ def load():
     lib.drl_last_lstm_variant.argtypes = [vp]
     lib.drl_last_lstm_variant.restype = C.c_char_p
     lib.drl_last_call_overlapped.argtypes = [vp]
+    lib.drl_comm_unique_id.argtypes = [vp, vp]
+    lib.drl_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.drl_allgather_scores.argtypes = [vp, vp, vp, C.c_int64]
+    lib.drl_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib

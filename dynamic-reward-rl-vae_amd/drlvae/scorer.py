@@ -271,6 +271,31 @@ class WindowScorer:
         self._check(self._lib.drl_profile_read(self._h, which, C.byref(ms), C.byref(n)), "drl_profile_read")
         return ms.value, n.value
 
+    # ------------------------------------------------------------------ the collective (RCCL)
+    def comm_unique_id(self) -> bytes:
+        """Rank 0 draws the communicator id; hand it to the other ranks (e.g. torch.distributed broadcast)."""
+        buf = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        self._check(self._lib.drl_comm_unique_id(self._h, buf), "drl_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, comm_id: bytes):
+        if len(comm_id) != _abi.COMM_ID_BYTES:
+            raise ValueError(f"the communicator id has {_abi.COMM_ID_BYTES} bytes")
+        buf = C.create_string_buffer(bytes(comm_id), _abi.COMM_ID_BYTES)
+        self._check(self._lib.drl_comm_init(self._h, int(rank), int(world), buf), "drl_comm_init")
+
+    def allgather(self, send, recv):
+        """All-gather of one contiguous device buffer per rank (torch tensors on this scorer's GPU):
+        ``recv`` holds world x ``send``; asynchronous on the scorer's stream."""
+        nbytes = send.numel() * send.element_size()
+        if not (send.is_contiguous() and recv.is_contiguous()) or recv.numel() * recv.element_size() % max(nbytes, 1):
+            raise ValueError("allgather needs contiguous buffers, recv a whole multiple of send")
+        self._check(self._lib.drl_allgather_scores(self._h, int(send.data_ptr()), int(recv.data_ptr()), nbytes),
+                    "drl_allgather_scores")
+
+    def comm_destroy(self):
+        self._check(self._lib.drl_comm_destroy(self._h), "drl_comm_destroy")
+
     @property
     def lstm_variant(self) -> str:
         return self._lib.drl_last_lstm_variant(self._h).decode()

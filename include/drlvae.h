@@ -189,6 +189,25 @@ int drl_al_get_samples(drl_ctx* ctx, const float* series, const int64_t* seg_off
                        const drl_score_opts* opts, const int32_t* already_selected, int n_selected, int N,
                        int32_t* out_idx, int32_t* n_out, float* margin_out);
 
+/* ---- the only collective of the path ------------------------------------------------------------ */
+
+/* The reference is single-process; windows shard across the GPUs of a node with weights
+ * replicated (one process and one drl_ctx per GPU) and the per-window scores are all-gathered over
+ * RCCL / xGMI (BASELINE.json north_star).  No counterpart in the reference.
+ *   drl_comm_unique_id  rank 0 draws an id (DRL_COMM_ID_BYTES bytes) and hands it to the other ranks
+ *                       by whatever channel the host has (torch.distributed store, MPI, a file);
+ *   drl_comm_init       every rank, with that id: collective, blocks until all nranks have called;
+ *   drl_allgather_scores  send_dev [bytes_per_rank] from every rank lands at
+ *                       recv_dev + r*bytes_per_rank on every rank; device pointers; asynchronous on
+ *                       the context's stream, i.e. ordered after the scoring call that filled send_dev;
+ *   drl_comm_destroy    also done by drl_destroy.
+ * RCCL is loaded on first use (dlopen), so the library loads on machines without it. */
+#define DRL_COMM_ID_BYTES 128
+int drl_comm_unique_id(drl_ctx* ctx, void* id_out);
+int drl_comm_init(drl_ctx* ctx, int rank, int nranks, const void* id);
+int drl_allgather_scores(drl_ctx* ctx, const void* send_dev, void* recv_dev, int64_t bytes_per_rank);
+int drl_comm_destroy(drl_ctx* ctx);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* With profiling on, every kernel launch of the scoring path is bracketed by hipEvents on the

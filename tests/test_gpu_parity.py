@@ -594,3 +594,29 @@ def test_c3_c4_full_size_series_are_periodic(scorer, F, N):
                                      vae_scale=scale, vae_clip=10.0), want_first)
     assert scorer.lstm_variant == "xproj+rec"
     assert first["q"].shape == (P, 2, 2)
+
+
+def test_allgather_entry_point_single_rank():
+    """drl_allgather_scores through the C-ABI with a one-rank communicator (the box has one GPU; RCCL
+    refuses two ranks on one device): the gathered block must be the rank's own block."""
+    import torch
+    from drlvae.scorer import WindowScorer
+    sc = WindowScorer(0)
+    try:
+        cid = sc.comm_unique_id()
+        assert len(cid) == 128
+        sc.comm_init(0, 1, cid)
+        dev = torch.device("cuda", 0)
+        send = torch.arange(100_003, dtype=torch.float32, device=dev)
+        recv = torch.zeros_like(send)
+        torch.cuda.synchronize()
+        sc.allgather(send, recv)
+        sc.synchronize()
+        assert torch.equal(send, recv)
+        with pytest.raises(RuntimeError, match="already"):
+            sc.comm_init(0, 1, cid)
+        sc.comm_destroy()
+        with pytest.raises(RuntimeError, match="drl_comm_init"):
+            sc.allgather(send, recv)
+    finally:
+        sc.close()
