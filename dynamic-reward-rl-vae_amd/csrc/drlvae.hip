@@ -723,6 +723,31 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
+        } else if (c->lstm.H == 128 && !od.in_scale &&
+                   (size_t)seg_offsets[n_seg] * 2048 <= ((size_t)64 << 30)) {   // projections: 2 KiB per sample
+            // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
+            // recurrence from the projections
+            const long long n_samples = seg_offsets[n_seg];
+            const size_t pbytes = (size_t)n_samples * 16 * 32 * sizeof(float);
+            if ((rc = ensure(c, c->pbuf, pbytes))) return rc;
+            XprojArgs xa;
+            xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
+            xa.P = (float*)c->pbuf.p;
+            hipLaunchKernelGGL(xproj_kernel<16>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
+            RecArgs ra;
+            ra.P = xa.P; ra.n_samples = n_samples;
+            ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
+            if (sh.tiles32 * a.S <= c->n_cu) {
+                a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
+                ra.l = a;
+                hipLaunchKernelGGL(lstm_h128p_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, ra);
+            } else {
+                a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+                ra.l = a;
+                const unsigned gx = std::min<unsigned>(sh.tiles64, std::max(1, c->n_cu / a.S));
+                hipLaunchKernelGGL(lstm_h128p_kernel<2>, dim3(gx, a.S), dim3(256), 0, c->stream, ra);
+            }
+            c->last_variant = "xproj+h128";
         } else if (c->lstm.NT == 8 && !od.in_scale &&
                    (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)64 << 30)) {   // projections: 1 KiB per sample (a chunk stays < 4 GiB)
             // H <= 64: project every sample once, then run the recurrences from the projections

@@ -682,7 +682,7 @@ struct XprojArgs {
 };
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void xproj_kernel(XprojArgs a) {
+__global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void xproj_kernel(XprojArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
     const long long n0 = ((long long)blockIdx.x * 4 + wave) * 32;
@@ -1080,6 +1080,158 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
             }
         }
         __syncthreads();        // h and the staged samples are rewritten by the next tile
+    }
+}
+
+// Multivariate H = 128 (any input width; e.g. SMD/WaDi sensors with the reference's default
+// n_hidden_dim = 128): the structure of lstm_h128i2_kernel — U stationary in the CU's register
+// file, h through LDS, two window groups half a step apart, persistent grid — with the input side
+// taken from the per-sample projections P of xproj_kernel<16> instead of an input k-step.  A group's
+// accumulators are free from its cell update until its next product, so the projections of its
+// next step are loaded straight into them in that gap and arrive under the other group's MFMAs.
+__device__ __forceinline__ void h128_mm(f32x16 (&acc)[4], const float (&U)[H128_UREG][64], const float* __restrict__ ul,
+                                        const float* __restrict__ hb, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+        const float b = hb[kk * 64 + lane];
+#pragma unroll
+        for (int tl = 0; tl < H128_UREG; ++tl) acc[tl] = mfma32(U[tl][kk], b, acc[tl]);
+#pragma unroll
+        for (int tl = H128_UREG; tl < 4; ++tl) acc[tl] = mfma32(ul[((tl - H128_UREG) * 64 + kk) * 64 + lane], b, acc[tl]);
+    }
+}
+
+template <int NG>
+__global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
+    const LstmArgs& a = ra.l;
+    __shared__ __attribute__((aligned(16))) float s_hA[64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_hB[64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_fw[16 * 2 * 16];   // flag row of Wx, accumulator order
+    __shared__ __attribute__((aligned(16))) float s_u[4][(4 - H128_UREG) * 64 * 64 + 4];
+    __shared__ float s_wout[128 * 8];
+    __shared__ SegLds s_seg;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    const int cand = blockIdx.y;
+    const int W = a.W;
+    seg_stage(s_seg, a.seg);
+    for (int i = threadIdx.x; i < 128 * a.A; i += 256) s_wout[i] = a.w_out[i];
+    for (int i = threadIdx.x; i < 16 * 2 * 16; i += 256) s_fw[i] = ra.flagw[i];
+
+    float U[H128_UREG][64];
+#pragma unroll
+    for (int tl = 0; tl < H128_UREG; ++tl) {
+        float tmp[64];
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) tmp[kk] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) U[tl][kk] = pin_agpr(tmp[kk]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* ul = &s_u[w][0];
+    for (int tl = H128_UREG; tl < 4; ++tl) {
+#pragma unroll 16
+        for (int kk = 0; kk < 64; ++kk)
+            ul[((tl - H128_UREG) * 64 + kk) * 64 + lane] = a.u[((size_t)kk * 16 + 4 * w + tl) * 64 + lane];
+    }
+    float* hA = s_hA;
+    float* hB = s_hB;
+    const float fb = a.forget_bias;
+    const char* __restrict__ Pb = reinterpret_cast<const char*>(ra.P);
+    const size_t chunk_bytes = (size_t)ra.n_samples * 32;
+    const bool flagged = a.flag_mode > 0;
+    const int wu = __builtin_amdgcn_readfirstlane(w);      // wave-uniform: the chunk bases stay scalar
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const SegHit sg = seg_lookup(s_seg, a.seg, tile);
+        const long long k0 = (long long)(tile - sg.tile0) * (32 * NG);
+        const int count = (int)(sg.Ks - k0 < 32 * NG ? sg.Ks - k0 : 32 * NG);
+        // this lane's window in each group (clamped to the tile's last window) and its row-0 sample
+        long long kw[2], nrow[2];
+        unsigned voff[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            int jw = g * 32 + j;
+            if (jw > count - 1) jw = count - 1;
+            kw[g] = k0 + jw;
+            nrow[g] = sg.samp0 + a.row0 + kw[g];
+            voff[g] = (unsigned)((size_t)nrow[g] * 32 + half * 16);
+        }
+        // projections of row t of group g into the accumulators of this wave's four gate tiles
+        auto load_p = [&](f32x16 (&acc)[4], int g, int t) {
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) acc[tl] = rec_load_p<16>(Pb, chunk_bytes, voff[g] + (unsigned)t * 32u, 4 * wu + tl);
+        };
+        auto add_flag = [&](f32x16 (&acc)[4], int g, int t) {
+            if (!flagged) return;
+            const float fl = a.flag_mode == 3 ? (float)cand
+                                              : synth_flag(a.flag_mode, kw[g], t, W, cand, a.flags, nrow[g] + t);
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const f32x16 wf = load_bias16(s_fw, 4 * w + tl, half);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tl][r] = fmaf(fl, wf[r], acc[tl][r]);
+            }
+        };
+
+        f32x16 accA[4], accB[4];
+        float cA[4][4], cB[4][4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { cA[tl][qd] = 0.0f; cB[tl][qd] = 0.0f; }
+
+        // step 0: h = 0, the projections alone
+        load_p(accA, 0, 0);
+        if (NG == 2) load_p(accB, 1, 0);
+        add_flag(accA, 0, 0);
+        h128_pointwise(accA, cA, hA, fb, lane, w);
+        if (W > 1) load_p(accA, 0, 1);
+        if (NG == 2) add_flag(accB, 1, 0);
+        __syncthreads();
+        for (int t = 1; t < W; ++t) {
+            const int tn = t + 1 < W ? t + 1 : t;
+            if (NG == 2) {
+                // phase 1: B's cell update of step t-1, B's next projections on their way, A's product
+                h128_pointwise(accB, cB, hB, fb, lane, w);
+                load_p(accB, 1, t);
+                add_flag(accA, 0, t);
+                h128_mm(accA, U, ul, hA, lane);
+                H128_SYNC();
+                // phase 2: the same with the groups swapped
+                h128_pointwise(accA, cA, hA, fb, lane, w);
+                load_p(accA, 0, tn);
+                add_flag(accB, 1, t);
+                h128_mm(accB, U, ul, hB, lane);
+                H128_SYNC();
+            } else {
+                add_flag(accA, 0, t);
+                h128_mm(accA, U, ul, hA, lane);
+                H128_SYNC();
+                h128_pointwise(accA, cA, hA, fb, lane, w);
+                load_p(accA, 0, tn);
+                H128_SYNC();
+            }
+        }
+        if (NG == 2) h128_pointwise(accB, cB, hB, fb, lane, w);
+        __syncthreads();
+
+        if (w < NG) {
+            const float* hb = w == 0 ? hA : hB;
+            const int jw = w * 32 + j;
+            for (int act = 0; act < a.A; ++act) {
+                float part = 0.0f;
+#pragma unroll 8
+                for (int kk = 0; kk < 64; ++kk)
+                    part = fmaf(hb[kk * 64 + lane], s_wout[((kk >> 2) * 8 + 2 * (kk & 3) + half) * a.A + act], part);
+                part += __shfl_xor(part, 32);
+                if (half == 0 && jw < count)
+                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -255,7 +255,7 @@ def test_multivariate_wadi_formulation(scorer, F, H, N):
     scorer.set_lstm(lstm)
     out = scorer.score(x, W, vae_lag=0, flag_mode="both", action_rule="wadi",
                        vae_center=center, vae_scale=scale, vae_clip=10.0)
-    assert scorer.lstm_variant == ("xproj+rec" if H <= 64 else "generic")
+    assert scorer.lstm_variant == ("xproj+rec" if H <= 64 else "xproj+h128")
     want = orc.score_series_multivariate(x, W, vae, lstm, center, scale, 10.0, dtype=np.float64)
     assert out["q"].shape == (N - W, 2, 2)
     np.testing.assert_allclose(out["err"], want["err"], rtol=RTOL)
@@ -264,6 +264,37 @@ def test_multivariate_wadi_formulation(scorer, F, H, N):
     safe = m > 2 * RTOL * np.abs(want["q"]).max(axis=(1, 2))
     assert np.array_equal(out["action"][safe], want["action"][safe])
     np.testing.assert_allclose(out["margin"], np.abs(out["q"][:, 1, 1] - out["q"][:, 0, 0]), rtol=0, atol=0)
+
+
+def test_multivariate_h128_large_call_matches_small_calls(scorer):
+    """Multivariate H = 128 (xproj + register-stationary recurrence): a large call runs 64-window
+    tiles on a persistent grid, a small one 32-window tiles; same bits, and the small one is
+    checked against the oracle."""
+    rng = np.random.default_rng(128)
+    F, N = 38, 5000
+    x = rng.random((N, F), dtype=np.float32)
+    lstm = synth_lstm(rng, F + 1, 128)
+    scorer.set_lstm(lstm)
+    kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", want=("q", "action"))
+    big = scorer.score(x, W, **kw)
+    assert scorer.lstm_variant == "xproj+h128" and big["q"].shape == (N - W, 2, 2)
+    for lo, n in ((0, 300), (1234, 333), (N - 200, 200)):
+        part = scorer.score(x[lo:lo + n], W, **kw)
+        for key in ("q", "action"):
+            assert np.array_equal(part[key].view(np.uint32), big[key][lo:lo + n - W].view(np.uint32)), (lo, key)
+    S = orc.states_multivariate(x[:300], W, 0, 300 - W)
+    want = orc.lstm_q(S.reshape(-1, W, F + 1), lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0,
+                      dtype=np.float64).reshape(300 - W, 2, 2)
+    rel = np.abs(big["q"][:300 - W].astype(np.float64) - want).reshape(300 - W, -1).max(axis=1) / np.abs(want).reshape(300 - W, -1).max(axis=1)
+    assert rel.max() <= RTOL, rel.max()
+    # quirk/explicit flags and a single candidate on the same path
+    fl = (rng.random(N) < 0.3).astype(np.float32)
+    one = scorer.score(x[:400], W, vae_lag=0, flag_mode="explicit", flags=fl[:400], want=("q",))["q"]
+    S1 = S[:, 0].copy()
+    idx = np.arange(300 - W)[:, None] + 1 + np.arange(W)[None, :]
+    S1[:, :, F] = fl[idx]
+    want1 = orc.lstm_q(S1, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float64)
+    assert_q_close(one[:300 - W], want1)
 
 
 def test_window_50_univariate(scorer):
