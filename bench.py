@@ -56,7 +56,7 @@ def a1_lengths():
     return np.diff(z["offsets"]).astype(np.int64)
 
 
-def workload(name, rank, windows):
+def workload(name, rank, windows, hidden=0):
     """Shapes of SURVEY.md §8(d).  Returns dict(series [N,F] float32, offsets, W, F, vae, lstm, opts)."""
     rng_w = np.random.default_rng(1234)
     if name in ("c1", "c2"):
@@ -81,7 +81,7 @@ def workload(name, rank, windows):
     elif name in ("c3", "c4"):
         W = 25
         F, n, seed = (38, 28479, 38) if name == "c3" else (123, int(windows) + W if windows else 172801, 123)
-        H = 64
+        H = hidden or 64                 # SURVEY 8d lists H=64 (WaDi QNet) and H=128 (the reference's default)
         rng = np.random.default_rng(seed + rank)
         if name == "c3":
             series = rng.random((n, F), dtype=np.float32)
@@ -97,7 +97,7 @@ def workload(name, rank, windows):
         scale = q[1] - q[0]
         scale[scale == 0] = 1.0
         desc = (f"{name.upper()}: synthetic {F}-sensor stream, N={n:,}, W=25, VAE {W*F}-128-10-128-{W*F}, "
-                f"LSTM I{F+1}/H64, two candidate states per window")
+                f"LSTM I{F+1}/H{H}, two candidate states per window")
         kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=center, vae_scale=scale,
                   vae_clip=10.0)
     else:
@@ -157,7 +157,7 @@ def pmc_traffic(name, variant):
     """HBM bytes per launch of the dominant kernel (the LSTM variant that ran) from the committed
     rocprofv3 PMC summary of the same workload (profiles/rNN/<workload>_pmc_summary.json), or None."""
     kern = {"h128i2": "lstm_h128i2_kernel", "h128i2_f16x3": "lstm_h128i2_f16x3_kernel",
-            "xproj+rec": "lstm_rec_kernel", "generic": "lstm_generic_kernel"}.get(variant, "lstm_")
+            "xproj+rec": "lstm_rec_kernel", "xproj+h128": "lstm_h128p_kernel", "generic": "lstm_generic_kernel"}.get(variant, "lstm_")
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{name}_pmc_summary.json"))):
@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--windows", type=float, default=0, help="windows per GPU for c5 (default 4e6) / c4")
     ap.add_argument("--lstm-math", default="fp32", choices=["fp32", "f16x3"],
                     help="recurrent product of the univariate H=128 LSTM: exact fp32 MFMA or 3-term f16 split")
+    ap.add_argument("--hidden", type=int, default=0, help="LSTM hidden width for c3/c4 (64 default, 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--collective", default="torch", choices=["torch", "abi"],
@@ -215,7 +216,7 @@ def main():
 
     if args.workload == "c5" and not args.windows:
         args.windows = 4e6
-    wl = workload(args.workload, rank, args.windows)
+    wl = workload(args.workload, rank, args.windows, args.hidden)
     from drlvae.scorer import WindowScorer
     sc = WindowScorer(local)
     sc.set_vae(wl["vae"])

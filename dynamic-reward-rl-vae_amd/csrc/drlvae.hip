@@ -732,8 +732,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             if ((rc = ensure(c, c->pbuf, pbytes))) return rc;
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
-            xa.P = (float*)c->pbuf.p;
-            hipLaunchKernelGGL(xproj_kernel<16>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
+            xa.P = (float*)c->pbuf.p; xa.nt_total = 16;
+            hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128), 2), dim3(256), 0, c->stream, xa);
             RecArgs ra;
             ra.P = xa.P; ra.n_samples = n_samples;
             ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
@@ -764,7 +764,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             }
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
-            xa.P = (float*)c->pbuf.p;
+            xa.P = (float*)c->pbuf.p; xa.nt_total = 8;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
             RecArgs ra;
             a.n_tiles = sh.tiles32;

@@ -679,25 +679,27 @@ struct XprojArgs {
     const float* wx;         // packed [ceil(I/2)][NT][64] (the flag row, feature F, is skipped here)
     const float* bias;       // packed [NT][2][16]
     float* P;                // [NT*4][n_samples][2][4]
+    int nt_total;            // gate tiles of the packed weights (8 or 16); blockIdx.y selects a group of NT
 };
 
 template <int NT>
-__global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void xproj_kernel(XprojArgs a) {
+__global__ __launch_bounds__(256, 2) void xproj_kernel(XprojArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
+    const int tile0 = blockIdx.y * NT;                       // H = 128: two passes of 8 gate tiles
     const long long n0 = ((long long)blockIdx.x * 4 + wave) * 32;
     if (n0 >= a.n_samples) return;
     const long long n = n0 + j < a.n_samples ? n0 + j : a.n_samples - 1;
     const float* __restrict__ xr = a.x + n * a.F;
     f32x16 acc[NT];
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl) acc[tl] = load_bias16(a.bias, tl, half);
+    for (int tl = 0; tl < NT; ++tl) acc[tl] = load_bias16(a.bias, tile0 + tl, half);
     const int nks = (a.F + 1) >> 1;
 #pragma unroll 2
     for (int ks = 0; ks < nks; ++ks) {
         const int feat = 2 * ks + half;
         const float bv = feat < a.F ? xr[feat] : 0.0f;
-        const float* __restrict__ wp = a.wx + ((size_t)ks * NT) * 64 + lane;
+        const float* __restrict__ wp = a.wx + ((size_t)ks * a.nt_total + tile0) * 64 + lane;
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(wp[tl * 64], bv, acc[tl]);
     }
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(256, (NT <= 8 ? 2 : 1)) void xproj_kernel(XprojArgs
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 f32x4 v = {acc[tl][4 * rg], acc[tl][4 * rg + 1], acc[tl][4 * rg + 2], acc[tl][4 * rg + 3]};
-                *reinterpret_cast<f32x4*>(a.P + ((((size_t)tl * 4 + rg) * a.n_samples + (n0 + j)) * 2 + half) * 4) = v;
+                *reinterpret_cast<f32x4*>(a.P + ((((size_t)(tile0 + tl)) * 4 + rg) * a.n_samples + (n0 + j)) * 8 + half * 4) = v;
             }
     }
 }
