@@ -703,7 +703,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.flag_mode = o->flag_mode; a.flags = d_flags; a.seg = seg;
         a.S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
         a.q = d_q;
-        const bool fast = c->lstm.I == 2 && c->lstm.H == 128 && F == 1 && W >= 2 && W + 65 <= H128_SV;
+        // hidden widths 65..128 are packed zero-padded to 16 gate tiles x 64 k-steps (padded units stay at h = 0)
+        const bool fast = c->lstm.I == 2 && c->lstm.NT == 16 && F == 1 && W >= 2 && W + 65 <= H128_SV;
         prof_begin(c, 0, c->stream);
         if (fast && c->lstm_math == 1 && c->lstm.has_split) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
@@ -723,7 +724,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
-        } else if (c->lstm.H == 128 && !od.in_scale &&
+        } else if (c->lstm.NT == 16 && !od.in_scale &&
                    (size_t)seg_offsets[n_seg] * 2048 <= ((size_t)64 << 30)) {   // projections: 2 KiB per sample
             // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
             // recurrence from the projections
@@ -949,7 +950,7 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
     prof_begin(c, 0, c->stream);
-    if (I == 2 && c->lstm.H == 128 && W >= 2) {
+    if (I == 2 && c->lstm.NT == 16 && W >= 2) {
         // the register-stationary univariate kernel, reading the states row by row
         if (sh.tiles32 <= c->n_cu) {
             hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, 1), dim3(256), 0, c->stream, a);

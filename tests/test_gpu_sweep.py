@@ -66,6 +66,9 @@ def test_univariate_random_shapes(scorer, seed):
         out = scorer.score(np.concatenate(norm), Wn, off, **kw)
     K = int(sum(max(0, n - Wn) for n in lens))
     assert out["err"].shape == (K,) and out["q"].shape == (K, A) and out["action"].shape == (K,)
+    # 65..128 hidden units: the register-stationary kernel (zero-padded to 128); up to 64: projections +
+    # recurrence, or the generic kernel when MinMax is applied on the device
+    assert scorer.lstm_variant == ("h128i2" if H > 64 else "generic" if device_minmax else "xproj+rec")
     pos = 0
     for v, fl, n in zip(norm, flags, lens):
         k = max(0, n - Wn)
@@ -118,6 +121,7 @@ def test_multivariate_random_shapes(scorer, seed):
                        vae_center=center, vae_scale=scale, vae_clip=clip)
     K = int(sum(max(0, n - Wn) for n in lens))
     assert out["q"].shape == (K, 2, 2)
+    assert scorer.lstm_variant == ("xproj+h128" if H > 64 else "xproj+rec")
     pos = 0
     for x, n in zip(xs, lens):
         k = max(0, n - Wn)
