@@ -724,7 +724,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2";
-        } else if (c->lstm.NT == 16 && !od.in_scale &&
+        } else if (c->lstm.NT == 16 &&
                    (size_t)seg_offsets[n_seg] * 2048 <= ((size_t)64 << 30)) {   // projections: 2 KiB per sample
             // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
             // recurrence from the projections
@@ -734,6 +734,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
             xa.P = (float*)c->pbuf.p; xa.nt_total = 16;
+            xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128), 2), dim3(256), 0, c->stream, xa);
             RecArgs ra;
             ra.P = xa.P; ra.n_samples = n_samples;
@@ -749,7 +750,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 hipLaunchKernelGGL(lstm_h128p_kernel<2>, dim3(gx, a.S), dim3(256), 0, c->stream, ra);
             }
             c->last_variant = "xproj+h128";
-        } else if (c->lstm.NT == 8 && !od.in_scale &&
+        } else if (c->lstm.NT == 8 &&
                    (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)64 << 30)) {   // projections: 1 KiB per sample (a chunk stays < 4 GiB)
             // H <= 64: project every sample once, then run the recurrences from the projections
             const long long n_samples = seg_offsets[n_seg];
@@ -766,6 +767,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
             xa.P = (float*)c->pbuf.p; xa.nt_total = 8;
+            xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
             RecArgs ra;
             a.n_tiles = sh.tiles32;

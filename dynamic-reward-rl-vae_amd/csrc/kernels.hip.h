@@ -680,6 +680,9 @@ struct XprojArgs {
     const float* bias;       // packed [NT][2][16]
     float* P;                // [NT*4][n_samples][2][4]
     int nt_total;            // gate tiles of the packed weights (8 or 16); blockIdx.y selects a group of NT
+    // optional per-series MinMax (reference env.py:78-79) applied to the samples on the way in
+    const long long* samp_off; int n_seg;
+    const float* in_scale; const float* in_offset;
 };
 
 template <int NT>
@@ -691,6 +694,13 @@ __global__ __launch_bounds__(256, 2) void xproj_kernel(XprojArgs a) {
     if (n0 >= a.n_samples) return;
     const long long n = n0 + j < a.n_samples ? n0 + j : a.n_samples - 1;
     const float* __restrict__ xr = a.x + n * a.F;
+    const bool has_norm = a.in_scale != nullptr;
+    float sc = 1.0f, of = 0.0f;
+    if (has_norm) {                                          // the series this lane's sample belongs to
+        int lo = 0, hi = a.n_seg;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.samp_off[mid] <= n) lo = mid; else hi = mid; }
+        sc = a.in_scale[lo]; of = a.in_offset[lo];
+    }
     f32x16 acc[NT];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) acc[tl] = load_bias16(a.bias, tile0 + tl, half);
@@ -698,7 +708,8 @@ __global__ __launch_bounds__(256, 2) void xproj_kernel(XprojArgs a) {
 #pragma unroll 2
     for (int ks = 0; ks < nks; ++ks) {
         const int feat = 2 * ks + half;
-        const float bv = feat < a.F ? xr[feat] : 0.0f;
+        float bv = feat < a.F ? xr[feat] : 0.0f;
+        if (has_norm && feat < a.F) bv = minmax_apply(bv, sc, of);
         const float* __restrict__ wp = a.wx + ((size_t)ks * a.nt_total + tile0) * 64 + lane;
 #pragma unroll
         for (int tl = 0; tl < NT; ++tl) acc[tl] = mfma32(wp[tl * 64], bv, acc[tl]);

@@ -66,9 +66,8 @@ def test_univariate_random_shapes(scorer, seed):
         out = scorer.score(np.concatenate(norm), Wn, off, **kw)
     K = int(sum(max(0, n - Wn) for n in lens))
     assert out["err"].shape == (K,) and out["q"].shape == (K, A) and out["action"].shape == (K,)
-    # 65..128 hidden units: the register-stationary kernel (zero-padded to 128); up to 64: projections +
-    # recurrence, or the generic kernel when MinMax is applied on the device
-    assert scorer.lstm_variant == ("h128i2" if H > 64 else "generic" if device_minmax else "xproj+rec")
+    # 65..128 hidden units: the register-stationary kernel (zero-padded to 128); up to 64: projections + recurrence
+    assert scorer.lstm_variant == ("h128i2" if H > 64 else "xproj+rec")
     pos = 0
     for v, fl, n in zip(norm, flags, lens):
         k = max(0, n - Wn)
@@ -117,8 +116,15 @@ def test_multivariate_random_shapes(scorer, seed):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     scorer.set_vae(vae)
     scorer.set_lstm(lstm)
-    out = scorer.score(np.concatenate(xs), Wn, off, vae_lag=0, flag_mode="both", action_rule="wadi",
-                       vae_center=center, vae_scale=scale, vae_clip=clip)
+    extra = {}
+    raw = xs
+    if seed % 3 == 0:                                   # per-series MinMax applied on the device
+        sc_ = rng.uniform(0.5, 2.0, n_seg).astype(np.float32)
+        of_ = rng.uniform(-0.5, 0.5, n_seg).astype(np.float32)
+        extra = dict(in_scale=sc_, in_offset=of_)
+        xs = [(x * s_ + o_).astype(np.float32) for x, s_, o_ in zip(raw, sc_, of_)]   # two fp32 roundings
+    out = scorer.score(np.concatenate(raw), Wn, off, vae_lag=0, flag_mode="both", action_rule="wadi",
+                       vae_center=center, vae_scale=scale, vae_clip=clip, **extra)
     K = int(sum(max(0, n - Wn) for n in lens))
     assert out["q"].shape == (K, 2, 2)
     assert scorer.lstm_variant == ("xproj+h128" if H > 64 else "xproj+rec")
