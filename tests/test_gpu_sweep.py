@@ -142,3 +142,21 @@ def test_multivariate_random_shapes(scorer, seed):
         assert np.array_equal(out["action"][pos:pos + k][safe], want["action"][safe])
         pos += k
     assert pos == K
+
+
+@pytest.mark.parametrize("Wn,F,H", [(1, 1, 128), (1, 3, 64), (2, 1, 8), (1, 5, 104), (191, 1, 128), (200, 1, 128)])
+def test_window_length_edges(scorer, Wn, F, H):
+    """W = 1 (no recurrent product at all), W = 2, and the longest windows the staged univariate
+    kernel takes (W + 65 <= 256) and the first one beyond (projection path)."""
+    rng = np.random.default_rng(Wn * 1000 + F * 10 + H)
+    N = Wn + 150
+    x = rng.random((N, F), dtype=np.float32)
+    lstm = synth_lstm(rng, F + 1, H)
+    scorer.set_lstm(lstm)
+    out = scorer.score(x if F > 1 else x[:, 0], Wn, vae_lag=0, flag_mode="both", action_rule="wadi", want=("q", "action"))
+    S = orc.states_multivariate(x, Wn)
+    want = orc.lstm_q(S.reshape(-1, Wn, F + 1), lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0,
+                      dtype=np.float64).reshape(N - Wn, 2, 2)
+    assert out["q"].shape == want.shape
+    tol = RTOL if Wn < 100 else 4 * RTOL          # 200 recurrent steps accumulate fp32 rounding
+    assert _nrel(out["q"], want) <= tol, (scorer.lstm_variant, _nrel(out["q"], want))
