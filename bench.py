@@ -229,15 +229,18 @@ def main():
     with torch.cuda.stream(stream):
         series = torch.from_numpy(wl["series"]).to(dev)
         # one score record block per rank: [err K | q K*S*2 | action K (i32 bits) | margin K], 4-byte
-        # words, so that the whole result travels in ONE all-gather per step
+        # words, so that the whole result travels in ONE all-gather per step.  Two sets of buffers: the
+        # all-gather of step i runs (on RCCL's stream) under the kernels of step i+1.
         words = K * (3 + 2 * S)
-        pack = torch.empty(words, dtype=torch.float32, device=dev)
-        out = {"err": pack[:K], "q": pack[K:K + 2 * S * K].view(K, S, 2),
-               "action": pack[K + 2 * S * K:2 * K + 2 * S * K].view(torch.int32), "margin": pack[2 * K + 2 * S * K:]}
+        nbuf = 2 if world > 1 and not args.no_allgather else 1
+        packs = [torch.empty(words, dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        outs = [{"err": p[:K], "q": p[K:K + 2 * S * K].view(K, S, 2),
+                 "action": p[K + 2 * S * K:2 * K + 2 * S * K].view(torch.int32), "margin": p[2 * K + 2 * S * K:]}
+                for p in packs]
         gathered = None
         if world > 1 and not args.no_allgather:
             # rank r's block lands at words [r*words, (r+1)*words)
-            gathered = torch.empty(world * words, dtype=torch.float32, device=cdev)
+            gathered = [torch.empty(world * words, dtype=torch.float32, device=cdev) for _ in range(nbuf)]
     stream.synchronize()
 
     use_abi = gathered is not None and args.collective == "abi" and not rehearse
@@ -246,15 +249,30 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         sc.comm_init(rank, world, ids[0])
 
+    pending = [None] * nbuf
+    counter = [0]
+
     def step():
-        sc.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
+        b = counter[0] % nbuf
+        counter[0] += 1
+        if pending[b] is not None:                       # its buffers are rewritten below
+            with torch.cuda.stream(stream):
+                pending[b].wait()
+            pending[b] = None
+        sc.score_dev(series, wl["W"], wl["offsets"], outs[b], **wl["kw"])
         if use_abi:
-            sc.allgather(pack, gathered)                 # RCCL on the scoring stream, no torch in between
+            sc.allgather(packs[b], gathered[b])          # RCCL on the scoring stream, no torch in between
         elif gathered is not None:
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gathered, pack.cpu() if rehearse else pack)
+                pending[b] = dist.all_gather_into_tensor(gathered[b], packs[b].cpu() if rehearse else packs[b],
+                                                         async_op=True)
 
     def fence():
+        with torch.cuda.stream(stream):
+            for b in range(nbuf):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
         stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -330,7 +348,7 @@ def main():
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
                        "collective": ("none" if gathered is None else "gloo all_gather (REHEARSAL, not a measurement)"
                                       if rehearse else ("one rccl all_gather (drl_allgather_scores) of the packed err/q/action/margin block per step"
-                                                       if use_abi else "one rccl all_gather of the packed err/q/action/margin block per step")),
+                                                       if use_abi else "one rccl all_gather of the packed err/q/action/margin block per step, overlapped with the next step's kernels")),
                        "lstm_kernel": variant,
                        "vae_and_lstm_kernels_overlap": overlapped},
             "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,
