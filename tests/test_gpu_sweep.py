@@ -160,3 +160,52 @@ def test_window_length_edges(scorer, Wn, F, H):
     assert out["q"].shape == want.shape
     tol = RTOL if Wn < 100 else 4 * RTOL          # 200 recurrent steps accumulate fp32 rounding
     assert _nrel(out["q"], want) <= tol, (scorer.lstm_variant, _nrel(out["q"], want))
+
+
+def test_repeated_calls_are_bit_identical():
+    """A missing barrier or a buffer reused too early shows up as run-to-run differences long before
+    it shows up as a wrong answer: score the same inputs many times, on every kernel family and with
+    the two-stream overlap forced on, and require identical bits every time."""
+    import os
+    from drlvae.scorer import WindowScorer
+    old = os.environ.get("DRLVAE_OVERLAP")
+    os.environ["DRLVAE_OVERLAP"] = "2"                  # read at drl_create
+    sc = WindowScorer(0)
+    if old is None:
+        del os.environ["DRLVAE_OVERLAP"]
+    else:
+        os.environ["DRLVAE_OVERLAP"] = old
+    try:
+        rng = np.random.default_rng(77)
+        cases = []
+        # univariate H=128: small call (32-window tiles) and large ragged call (64-window tiles, persistent)
+        vae_u, _, _ = _rand_vae(rng, 25)
+        lstm_u = synth_lstm(rng, 2, 128)
+        lens = [int(n) for n in rng.integers(700, 1500, 40)]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        big = rng.random(int(off[-1]), dtype=np.float32)
+        cases.append(("uni-small", vae_u, lstm_u, big[:1400], None, dict(flag_mode="quirk"), "fp32"))
+        cases.append(("uni-large", vae_u, lstm_u, big, off, dict(flag_mode="quirk"), "fp32"))
+        cases.append(("uni-large-f16x3", vae_u, lstm_u, big, off, dict(flag_mode="zeros"), "f16x3"))
+        # multivariate, wide VAE, both LSTM paths
+        for H in (64, 128):
+            F = 38
+            vae_m = synth_vae(rng, [25 * F, 128, 10, 128, 25 * F], 1)
+            x = rng.random((6000, F), dtype=np.float32)
+            cen = rng.uniform(0.3, 0.7, 25 * F).astype(np.float32)
+            scl = rng.uniform(0.2, 0.6, 25 * F).astype(np.float32)
+            cases.append((f"multi-H{H}", vae_m, synth_lstm(rng, F + 1, H), x, None,
+                          dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=cen, vae_scale=scl,
+                               vae_clip=10.0), "fp32"))
+        for name, vae, lstm, x, offs, kw, math in cases:
+            sc.set_vae(vae)
+            sc.set_lstm(lstm)
+            sc.set_lstm_math(math)
+            first = sc.score(x, 25, offs, **kw)
+            assert sc.overlapped
+            for rep in range(25):
+                again = sc.score(x, 25, offs, **kw)
+                for key in first:
+                    assert np.array_equal(first[key].view(np.uint32), again[key].view(np.uint32)), (name, key, rep)
+    finally:
+        sc.close()
