@@ -81,6 +81,8 @@ struct drl_ctx {
     DevBuf vae_w, lstm_w;       // packed weights
     DevBuf seg;                 // segment tables
     DevBuf opt;                 // per-series / per-column option arrays
+    std::vector<float> opt_host;   // what `opt` holds (re-uploaded only when it changes)
+    size_t opt_S = 0, opt_P = 0;
     DevBuf pbuf;                // per-sample input projections of the H<=64 LSTM path
     DevBuf al_keys, al_keys2, al_idx, al_idx2, al_tmp, al_sel;   // active-learning selection scratch
     bool rec_attr_set = false;
@@ -566,39 +568,40 @@ struct OptDev {
     const float* inv_scale = nullptr;
 };
 
-// Uploads the small host-side option arrays (per series / per flattened column).
+// Uploads the small host-side option arrays (per series / per flattened column).  They are gathered
+// into one block; when the block equals the one already on the device (the usual case: the same
+// scaler for every call) nothing is copied, otherwise the stream is drained first — an earlier
+// asynchronous call may still be reading the old block.
 int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d) {
-    size_t n = 0;
-    if (o->in_scale) n += 2 * up16(n_seg);
-    if (o->vae_center) n += 3 * up32(D);
-    if (!n) return DRL_OK;
-    int rc = ensure(c, c->opt, n * sizeof(float));
-    if (rc) return rc;
-    float* base = (float*)c->opt.p;
-    size_t off = 0;
-    // synchronous small copies: the sources are caller memory that may go away after the call
-    if (o->in_scale) {
-        if (!o->in_offset) return fail(c, DRL_ERR_ARG, "opts.in_scale given without in_offset");
-        HIP_TRY(c, hipMemcpyAsync(base + off, o->in_scale, n_seg * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        d.in_scale = base + off; off += up16(n_seg);
-        HIP_TRY(c, hipMemcpyAsync(base + off, o->in_offset, n_seg * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        d.in_offset = base + off; off += up16(n_seg);
+    if (o->in_scale && !o->in_offset) return fail(c, DRL_ERR_ARG, "opts.in_scale given without in_offset");
+    if (o->vae_center && !o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
+    if (!o->in_scale && !o->vae_center) return DRL_OK;
+    const size_t S = o->in_scale ? up16(n_seg) : 0;
+    const size_t P = o->vae_center ? up32(D) : 0;      // padded to a whole 32-feature tile (center 0, scale 1):
+    std::vector<float> h(2 * S + 3 * P, 0.0f);          // vae_wide_kernel streams them per tile
+    if (S) {
+        memcpy(h.data(), o->in_scale, n_seg * sizeof(float));
+        memcpy(h.data() + S, o->in_offset, n_seg * sizeof(float));
     }
-    if (o->vae_center) {
-        if (!o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
-        // padded to a whole 32-feature tile (center 0, scale 1): vae_wide_kernel streams them per tile
-        const size_t P = up32(D);
-        std::vector<float> h(3 * P);
-        for (size_t i = 0; i < P; ++i) {
-            const bool in = i < (size_t)D;
-            h[i] = in ? o->vae_center[i] : 0.0f;
-            h[P + i] = in ? o->vae_scale[i] : 1.0f;
-            h[2 * P + i] = in ? (float)(1.0 / (double)o->vae_scale[i]) : 1.0f;
-        }
-        HIP_TRY(c, hipMemcpy(base + off, h.data(), 3 * P * sizeof(float), hipMemcpyHostToDevice));
-        d.center = base + off; d.scale = base + off + P; d.inv_scale = base + off + 2 * P; off += 3 * P;
+    float* hc = h.data() + 2 * S;
+    for (size_t i = 0; i < P; ++i) {
+        const bool in = i < (size_t)D;
+        hc[i] = in ? o->vae_center[i] : 0.0f;
+        hc[P + i] = in ? o->vae_scale[i] : 1.0f;
+        hc[2 * P + i] = in ? (float)(1.0 / (double)o->vae_scale[i]) : 1.0f;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!(c->opt.p && c->opt_S == S && c->opt_P == P && c->opt_host.size() == h.size() &&
+          memcmp(c->opt_host.data(), h.data(), h.size() * sizeof(float)) == 0)) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int rc = ensure(c, c->opt, h.size() * sizeof(float));
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy(c->opt.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+        c->opt_host.swap(h);
+        c->opt_S = S; c->opt_P = P;
+    }
+    const float* base = (const float*)c->opt.p;
+    if (S) { d.in_scale = base; d.in_offset = base + S; }
+    if (P) { d.center = base + 2 * S; d.scale = base + 2 * S + P; d.inv_scale = base + 2 * S + 2 * P; }
     return DRL_OK;
 }
 
