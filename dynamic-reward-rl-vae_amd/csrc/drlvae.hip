@@ -363,7 +363,13 @@ const char* drl_last_error(drl_ctx* c) { return c ? c->err.c_str() : g_create_er
 
 int drl_set_stream(drl_ctx* c, void* s) {
     if (!c) return DRL_ERR_ARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
+    if (ns != c->stream) {
+        // work queued on the old stream still uses the context's buffers: the two streams are not ordered
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->stream = ns;
+    }
     return DRL_OK;
 }
 
