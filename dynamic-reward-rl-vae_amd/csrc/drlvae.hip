@@ -961,7 +961,11 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
     prof_begin(c, 0, c->stream);
-    if (I == 2 && c->lstm.NT == 16 && W >= 2) {
+    if (I == 2 && c->lstm.NT == 16 && B <= 4) {
+        // the per-step call of the reference's RL loop: a matrix-vector kernel, one workgroup per state
+        hipLaunchKernelGGL(lstm_h128_gemv_kernel, dim3((unsigned)B), dim3(512), 0, c->stream, a);
+        c->last_variant = "h128-gemv";
+    } else if (I == 2 && c->lstm.NT == 16 && W >= 2) {
         // the register-stationary univariate kernel, reading the states row by row
         if (sh.tiles32 <= c->n_cu) {
             hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, 1), dim3(256), 0, c->stream, a);

@@ -1248,6 +1248,62 @@ __global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
     }
 }
 
+// estimator.predict at batch 1 or 2 — the reference's call at every environment step
+// (myasp-A1.py:224-229 policy, env.py:143 candidate states).  A 32-column MFMA tile would be 97 %
+// empty, so this is a matrix-vector kernel on the VALU: one workgroup of 512 threads per state,
+// thread r owns gate row r of the packed U (128 weights in registers), h_t is broadcast from LDS.
+// The products are accumulated in the order the MFMA kernels use (bias, value, flag, units 0..127),
+// so the result is bit-identical to theirs.
+__global__ __launch_bounds__(512, 1) void lstm_h128_gemv_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_h[2][128];
+    __shared__ float s_part[2 * 8];
+    const int r = threadIdx.x;                  // packed gate row: tile r>>5, row-in-tile r&31
+    const int tau = r >> 5, i = r & 31;
+    const int b = blockIdx.x;                   // the state
+    const int W = a.W;
+    float U[128];
+#pragma unroll
+    for (int u = 0; u < 128; ++u) {
+        const int kk = (u >> 3) * 4 + ((u & 7) >> 1), half = u & 1;
+        U[u] = a.u[((size_t)kk * 16 + tau) * 64 + half * 32 + i];
+    }
+    const float wv = a.wx[tau * 64 + i], wf = a.wx[tau * 64 + 32 + i];
+    const float bias = a.bias[(tau * 2 + ((i >> 2) & 1)) * 16 + (i & 3) + 4 * (i >> 3)];
+    const float* __restrict__ x = a.x + (long long)b * a.win_stride;
+    if (r < 128) { s_h[0][r] = 0.0f; s_h[1][r] = 0.0f; }
+    float c = 0.0f;
+    __syncthreads();
+    for (int t = 0; t < W; ++t) {
+        const float* __restrict__ hs = s_h[t & 1];
+        float z = bias;
+        z = fmaf(wv, x[(long long)t * a.row_stride], z);
+        z = fmaf(wf, x[(long long)t * a.row_stride + 1], z);
+        if (t > 0) {
+#pragma unroll
+            for (int u = 0; u < 128; ++u) z = fmaf(U[u], hs[u], z);
+        }
+        // the four gates of a unit sit in four consecutive lanes
+        const int q0 = (threadIdx.x & 63) & ~3;
+        const float zi = __shfl(z, q0 + 0), zj = __shfl(z, q0 + 1), zf = __shfl(z, q0 + 2), zo = __shfl(z, q0 + 3);
+        const float hv = lstm_cell(zi, zj, zf, zo, a.forget_bias, c);
+        if ((i & 3) == 0) s_h[(t + 1) & 1][8 * tau + (i >> 2)] = hv;
+        __syncthreads();
+    }
+    // Q head in the order of the MFMA kernels: even and odd units as two chains, then their sum
+    const float* __restrict__ hs = s_h[W & 1];
+    if (r < 2 * a.A) {
+        const int act = r >> 1, half = r & 1;
+        float part = 0.0f;
+        for (int kk = 0; kk < 64; ++kk) {
+            const int unit = (kk >> 2) * 8 + 2 * (kk & 3) + half;
+            part = fmaf(hs[unit], a.w_out[unit * a.A + act], part);
+        }
+        s_part[r] = part;
+    }
+    __syncthreads();
+    if (r < a.A) a.q[(long long)b * a.A + r] = (s_part[2 * r] + s_part[2 * r + 1]) + a.b_out[r];
+}
+
 // ------------------------------------------------------------------------------------------------
 // action + AL margin from Q (reference myasp-A1.py:227, 255; myasp-wadi.py:328)
 __global__ void finalize_kernel(const float* __restrict__ q, long long K, int S, int A, int rule,

@@ -201,7 +201,13 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     assert scorer.lstm_variant == "h128i2"              # explicit states through the register-stationary kernel
     assert_q_close(q, orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
     one = scorer.q_predict(S[:1])                       # the reference's batch-1 call pattern
-    assert np.array_equal(one, q[:1])
+    assert scorer.lstm_variant == "h128-gemv"           # matrix-vector kernel, same accumulation order:
+    assert np.array_equal(one.view(np.uint32), q[:1].view(np.uint32))     # bit-identical to the MFMA kernel
+    for bsz in (2, 3, 4):
+        few = scorer.q_predict(S[10:10 + bsz])
+        assert scorer.lstm_variant == "h128-gemv"
+        assert np.array_equal(few.view(np.uint32), q[10:10 + bsz].view(np.uint32))
+    assert np.array_equal(scorer.q_predict(S[:5]).view(np.uint32), q[:5].view(np.uint32)) and scorer.lstm_variant == "h128i2"
     # the same states scored as sliding windows of the series give the same bits
     slid = scorer.score(v, W, flag_mode="quirk", want=("q",))["q"][:300]
     assert np.array_equal(slid.view(np.uint32), q.view(np.uint32))
