@@ -799,8 +799,11 @@ __device__ __forceinline__ void rec_step(f32x16 (&pq)[4], float (&aq)[2][8], flo
         for (int qd = 0; qd < 4; ++qd) h[tl][qd] = hn[tl][qd];
 }
 
+#ifndef REC_WAVES_PER_SIMD
+#define REC_WAVES_PER_SIMD 1
+#endif
 template <int NT, bool FLAGGED>
-__global__ __launch_bounds__(256, 1) void lstm_rec_kernel(RecArgs ra) {
+__global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64] | flag row [NT][2][16]
     static_assert(NT % 4 == 0, "the projection ring assumes a multiple of 4 gate tiles");
     const LstmArgs& a = ra.l;
