@@ -352,6 +352,22 @@ __device__ __forceinline__ const float* vw_side_stream(const VaeArgs& a, const f
 #else
 #define VW_SYNC() __syncthreads()
 #endif
+// Last-layer epilogue of one 32-feature output tile: activation, input transform, squared error.
+template <bool SCALED, int ACT, bool MASKED>
+__device__ __forceinline__ float vw_epilogue(const f32x16& acc, const float (&xv)[16], const float (&cen)[16],
+                                             const float (&isc)[16], float clip, int d0, int D, int half, float sq) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float y = apply_act(acc[r], ACT);
+        float x = xv[r];
+        if (SCALED) x = __builtin_amdgcn_fmed3f((x - cen[r]) * isc[r], -clip, clip);
+        float df = y - x;
+        if (MASKED) df = (d0 + rowmap(r, half) < D) ? df : 0.0f;      // the feature tail of the last tile is padding
+        sq = fmaf(df, df, sq);
+    }
+    return sq;
+}
+
 template <bool SCALED>
 __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArgs a, int xr_floats) {
     extern __shared__ __attribute__((aligned(16))) float vw_smem[];
@@ -508,14 +524,17 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
 #if VW_ABL == 4
                 sq += acc[0] + acc[15] + xv[0];
 #else
-                act16(acc, act);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float x = xv[r];
-                    if (SCALED) x = __builtin_amdgcn_fmed3f((x - cen[r]) * isc[r], -clip, clip);
-                    const float df = (ot * 32 + rowmap(r, half) < D) ? acc[r] - x : 0.0f;
-                    sq = fmaf(df, df, sq);
-                }
+                // activation code and "is this the padded last tile" are wave-uniform: one straight-line
+                // epilogue per combination, no per-element selects or copies
+                const bool masked = ot + 1 == nout;
+                if (act == 3) sq = masked ? vw_epilogue<SCALED, 3, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
+                                          : vw_epilogue<SCALED, 3, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
+                else if (act == 2) sq = masked ? vw_epilogue<SCALED, 2, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
+                                               : vw_epilogue<SCALED, 2, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
+                else if (act == 1) sq = masked ? vw_epilogue<SCALED, 1, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
+                                               : vw_epilogue<SCALED, 1, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
+                else sq = masked ? vw_epilogue<SCALED, 0, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
+                                 : vw_epilogue<SCALED, 0, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
 #endif
             }
             if (more) {
