@@ -202,6 +202,13 @@ class RewardFunction:
         return [0, 0]
 
 
+def update_dynamic_coef_proportional(current_coef, episode_reward, target_reward=100.0, alpha=0.01, min_coef=0.1,
+                                     max_coef=10.0):
+    """The dynamic reward coefficient's per-episode update (reference myasp-A1.py:235-238; called with
+    target_reward=0.0, alpha=0.001 at :455): scalar host arithmetic, same signature."""
+    return max(min(current_coef + alpha * (target_reward - episode_reward), max_coef), min_coef)
+
+
 def penalty_array(values, n_steps: int, vae: KerasVAE, center=None, scale=None, clip: float = 10.0):
     """The module-level ``penalty_array`` of the WaDi driver (reference myasp-wadi.py:130-149):
     ``values`` (N, F) raw sensors -> float array (N,), zeros for the first n_steps-1 entries, then

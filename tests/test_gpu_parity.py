@@ -91,6 +91,18 @@ def test_c1_real1_quirk(scorer, a1, ckpt_a1):
     assert np.array_equal(out["action"], (out["q"][:, 1] > out["q"][:, 0]).astype(np.int32))
 
 
+def test_c1_survey_anchors_on_the_gpu(scorer, a1, ckpt_a1):
+    """SURVEY.md appendix C (the survey's independent numpy probe of real_1.csv), reproduced by the HIP path."""
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    out = scorer.score(a1["series"][0], W, flag_mode="zeros")
+    e = out["err"]
+    assert (round(float(e.min()), 5), round(float(e.mean(dtype=np.float64)), 5), round(float(e.max()), 5)) == (0.08446, 0.16817, 0.2089)
+    np.testing.assert_allclose(out["q"][:3], [[30.0847, 28.5161], [30.1293, 28.4941], [30.2094, 28.6030]], atol=6e-5)
+    assert int(out["action"].sum()) == 1 and len(out["action"]) == 1395
+
+
 def test_c1_zeros_and_explicit_flags(scorer, a1, ckpt_a1):
     lstm, vae = ckpt_a1
     scorer.set_vae(vae)

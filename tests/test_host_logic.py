@@ -137,3 +137,11 @@ def test_sharded_scoring_equals_single_process_gloo_world2(ckpt_a1):
             for k in ("err", "q", "margin"):
                 np.testing.assert_allclose(got[k], want[k], rtol=2e-6, atol=1e-6, err_msg=f"{mode}/{k}/rank{rank}")
             np.testing.assert_array_equal(got["action"], want["action"])
+
+
+def test_dynamic_coef_update_matches_reference_formula():
+    """reference myasp-A1.py:235-238 / :455 (target 0, alpha 0.001, clip to [0.1, 10])."""
+    from drlvae.compat import update_dynamic_coef_proportional as upd
+    assert upd(1.0, -500.0, target_reward=0.0, alpha=0.001) == pytest.approx(1.5)
+    assert upd(1.0, 2000.0, target_reward=0.0, alpha=0.001) == 0.1
+    assert upd(9.9, -5000.0, target_reward=0.0, alpha=0.001) == 10.0

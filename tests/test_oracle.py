@@ -99,3 +99,16 @@ def test_multivariate_alignment():
     np.testing.assert_array_equal(win[5], x[5:30].reshape(-1))
     pen = orc.penalty_array(np.arange(36), W)
     assert len(pen) == 60 and pen[23] == 0 and pen[24] == 0 and pen[25] == 1
+
+
+def test_survey_appendix_c_anchors(a1, ckpt_a1):
+    """figures from the survey's own, independent numpy probe of the same
+    checkpoint on real_1.csv (rounded there to 4-5 digits)."""
+    lstm, vae = ckpt_a1
+    v = a1["series"][0]
+    assert len(v) == 1420
+    out = orc.score_series_univariate(v, 25, vae, lstm, "zeros", dtype=np.float32)
+    assert (round(float(out["err"].min()), 5), round(float(out["err"].mean()), 5), round(float(out["err"].max()), 5)) \
+        == (0.08446, 0.16817, 0.2089)
+    np.testing.assert_allclose(out["q"][:3], [[30.0847, 28.5161], [30.1293, 28.4941], [30.2094, 28.6030]], atol=6e-5)
+    assert int(out["action"].sum()) == 1 and len(out["action"]) == 1395
