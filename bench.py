@@ -146,7 +146,24 @@ def cpu_baseline(wl):
                 break
         passes += 1
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "windows/s", "cores": int(cores), "kind": "port",
+    # the reference's own call pattern (one vae.predict + one estimator.predict per window, batch 1:
+    # SURVEY.md 3.1), ~2 s of it, reported beside the batched figure
+    b1 = None
+    if F == 1:
+        v = x[off[0]:off[1], 0]
+        vae, lstm = wl["vae"], wl["lstm"]
+        n1, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 2.0 and n1 + W + 1 < len(v):
+            xw = v[n1:n1 + W][None, :]
+            rec = orc.vae_forward(xw, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], 10.0)
+            orc.recon_error(xw, rec)
+            st = np.zeros((1, W, 2), np.float32)
+            st[0, :, 0] = v[n1 + 1:n1 + 1 + W]
+            orc.greedy_action(orc.lstm_q(st, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0))
+            n1 += 1
+        b1 = {"value": n1 / (time.perf_counter() - t1), "unit": "windows/s",
+              "sample": f"{n1} windows, one batch-1 VAE call + one batch-1 LSTM call each (the reference's call pattern)"}
+    return {"value": done / dt, "unit": "windows/s", "cores": int(cores), "kind": "port", "call_pattern_batch1": b1,
             "sample": f"{done:,} windows ({passes} pass(es) over the head of the same workload) in {dt:.1f} s; "
                       f"oracle/ref_path.py = numpy fp32 restatement, whole-series batches through BLAS "
                       f"(not the reference's TF path, which cannot run here; its batch-1 call pattern is "
