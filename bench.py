@@ -377,6 +377,11 @@ def main():
                          "flop_per_launch": wl["lstm_flops"] * K,
                          "vae_kernel_avg_ms": vae_ms / max(vae_n, 1)},
         }
+        tr = res["roofline"]["traffic"]
+        if tr and lstm_avg_s > 0:
+            # the other roofline, for the record: this path sits at a fraction of a percent of HBM
+            res["roofline"]["hbm_achieved_GBps"] = tr / lstm_avg_s / 1e9
+            res["roofline"]["hbm_frac_of_8TBps"] = tr / lstm_avg_s / 8e12
         if alt is not None:
             res["alt_arithmetic"] = alt
         if world == 1 and not args.no_cpu_baseline:
