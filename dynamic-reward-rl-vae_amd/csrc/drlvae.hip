@@ -93,7 +93,7 @@ struct drl_ctx {
     Prof prof;
     const char* last_variant = "none";
     const char* last_vae_variant = "none";
-    size_t wide_lds_set = 0;
+    size_t wide_lds_set = 0, gemv_lds_set = 0;
     // the segment tables of the last call stay valid on the device while the same series layout is scored again
     std::vector<int64_t> seg_key;
     long long seg_K = 0;
@@ -961,10 +961,20 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
     prof_begin(c, 0, c->stream);
-    if (I == 2 && c->lstm.NT == 16 && B <= 4) {
+    const int gv_rows = 32 * c->lstm.NT, gv_ip = (I + 3) & ~3;
+    const size_t gv_lds = ((size_t)W * gv_ip + (size_t)W * gv_rows) * sizeof(float);
+    if (B <= 4 && W <= GEMV_WMAX && gv_lds <= 150 * 1024) {
         // the per-step call of the reference's RL loop: a matrix-vector kernel, one workgroup per state
-        hipLaunchKernelGGL(lstm_h128_gemv_kernel, dim3((unsigned)B), dim3(512), 0, c->stream, a);
-        c->last_variant = "h128-gemv";
+        if (gv_lds > c->gemv_lds_set) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_gemv_kernel<8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_gemv_kernel<16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            c->gemv_lds_set = 150 * 1024;
+        }
+        if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_gemv_kernel<8>, dim3((unsigned)B), dim3(256), gv_lds, c->stream, a);
+        else hipLaunchKernelGGL(lstm_gemv_kernel<16>, dim3((unsigned)B), dim3(512), gv_lds, c->stream, a);
+        c->last_variant = "gemv";
     } else if (I == 2 && c->lstm.NT == 16 && W >= 2) {
         // the register-stationary univariate kernel, reading the states row by row
         if (sh.tiles32 <= c->n_cu) {

@@ -1270,39 +1270,79 @@ __global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
     }
 }
 
-// estimator.predict at batch 1 or 2 — the reference's call at every environment step
-// (myasp-A1.py:224-229 policy, env.py:143 candidate states).  A 32-column MFMA tile would be 97 %
-// empty, so this is a matrix-vector kernel on the VALU: one workgroup of 512 threads per state,
-// thread r owns gate row r of the packed U (128 weights in registers), h_t is broadcast from LDS.
-// The products are accumulated in the order the MFMA kernels use (bias, value, flag, units 0..127),
-// so the result is bit-identical to theirs.
-__global__ __launch_bounds__(512, 1) void lstm_h128_gemv_kernel(LstmArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_h[2][128];
+// estimator.predict at batch 1..4 — the reference's call at every environment step
+// (myasp-A1.py:224-229 policy, env.py:143 candidate states; myasp-wadi.py:326-328 Q of s0 and s1).
+// A 32-column MFMA tile would be 97 % empty, so this is a matrix-vector kernel on the VALU: one
+// workgroup of 32*NT threads per state, thread r owns gate row r of the packed weights (its H
+// recurrent weights in registers), h_t is broadcast from LDS.  The input side, which does not depend
+// on h, is done first for all W rows (the state staged in LDS, the input weights streamed once).
+// Every sum runs in the order the MFMA kernels use (bias, input features 0..I-1, units 0..H-1), so
+// the result is bit-identical to theirs.  W <= GEMV_WMAX.
+#define GEMV_WMAX 64
+template <int NT>
+__global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
+    constexpr int ROWS = 32 * NT, HP = 8 * NT;
+    extern __shared__ __attribute__((aligned(16))) float gv_smem[];
+    __shared__ __attribute__((aligned(16))) float s_h[2][HP];
     __shared__ float s_part[2 * 8];
     const int r = threadIdx.x;                  // packed gate row: tile r>>5, row-in-tile r&31
     const int tau = r >> 5, i = r & 31;
     const int b = blockIdx.x;                   // the state
-    const int W = a.W;
-    float U[128];
-#pragma unroll
-    for (int u = 0; u < 128; ++u) {
-        const int kk = (u >> 3) * 4 + ((u & 7) >> 1), half = u & 1;
-        U[u] = a.u[((size_t)kk * 16 + tau) * 64 + half * 32 + i];
+    const int W = a.W, I = a.I;
+    const int IP = (I + 3) & ~3;                // row stride of the staged state
+    float* s_x = gv_smem;                       // [W][IP], zero padded
+    float* s_zx = gv_smem + W * IP;             // [W][ROWS]: input part of every step's pre-activations
+    {
+        const float* __restrict__ x = a.x + (long long)b * a.win_stride;
+        for (int e = r; e < W * IP; e += ROWS) {
+            const int t = e / IP, f = e - t * IP;
+            s_x[e] = f < I ? x[(long long)t * a.row_stride + f] : 0.0f;
+        }
+        if (r < HP) { s_h[0][r] = 0.0f; s_h[1][r] = 0.0f; }
     }
-    const float wv = a.wx[tau * 64 + i], wf = a.wx[tau * 64 + 32 + i];
+    float U[HP];
+#pragma unroll
+    for (int u = 0; u < HP; ++u) {
+        const int kk = (u >> 3) * 4 + ((u & 7) >> 1), half = u & 1;
+        U[u] = a.u[((size_t)kk * NT + tau) * 64 + half * 32 + i];
+    }
     const float bias = a.bias[(tau * 2 + ((i >> 2) & 1)) * 16 + (i & 3) + 4 * (i >> 3)];
-    const float* __restrict__ x = a.x + (long long)b * a.win_stride;
-    if (r < 128) { s_h[0][r] = 0.0f; s_h[1][r] = 0.0f; }
-    float c = 0.0f;
     __syncthreads();
+
+    // input part: zx[t] = bias + sum_f wx[f] * x[t][f], f ascending; four features per pass
+    {
+        float zx[GEMV_WMAX];
+#pragma unroll
+        for (int t = 0; t < GEMV_WMAX; ++t) zx[t] = bias;
+        for (int f0 = 0; f0 < IP; f0 += 4) {
+            float w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = f0 + q;           // wx is packed [ceil(I/2)][NT][64]: (f>>1, tau, (f&1)*32 + i); zero beyond I
+                w[q] = f < I ? a.wx[((size_t)(f >> 1) * NT + tau) * 64 + (f & 1) * 32 + i] : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < GEMV_WMAX; ++t) {
+                if (t < W) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(s_x + t * IP + f0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (f0 + q < I) zx[t] = fmaf(w[q], xv[q], zx[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < GEMV_WMAX; ++t)
+            if (t < W) s_zx[t * ROWS + r] = zx[t];          // read back by this thread only
+    }
+
+    float c = 0.0f;
     for (int t = 0; t < W; ++t) {
         const float* __restrict__ hs = s_h[t & 1];
-        float z = bias;
-        z = fmaf(wv, x[(long long)t * a.row_stride], z);
-        z = fmaf(wf, x[(long long)t * a.row_stride + 1], z);
+        float z = s_zx[t * ROWS + r];
         if (t > 0) {
 #pragma unroll
-            for (int u = 0; u < 128; ++u) z = fmaf(U[u], hs[u], z);
+            for (int u = 0; u < HP; ++u) z = fmaf(U[u], hs[u], z);
         }
         // the four gates of a unit sit in four consecutive lanes
         const int q0 = (threadIdx.x & 63) & ~3;
@@ -1316,9 +1356,9 @@ __global__ __launch_bounds__(512, 1) void lstm_h128_gemv_kernel(LstmArgs a) {
     if (r < 2 * a.A) {
         const int act = r >> 1, half = r & 1;
         float part = 0.0f;
-        for (int kk = 0; kk < 64; ++kk) {
+        for (int kk = 0; kk < 4 * NT; ++kk) {
             const int unit = (kk >> 2) * 8 + 2 * (kk & 3) + half;
-            part = fmaf(hs[unit], a.w_out[unit * a.A + act], part);
+            part = fmaf(hs[unit], unit < a.H ? a.w_out[unit * a.A + act] : 0.0f, part);
         }
         s_part[r] = part;
     }

@@ -213,11 +213,11 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     assert scorer.lstm_variant == "h128i2"              # explicit states through the register-stationary kernel
     assert_q_close(q, orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
     one = scorer.q_predict(S[:1])                       # the reference's batch-1 call pattern
-    assert scorer.lstm_variant == "h128-gemv"           # matrix-vector kernel, same accumulation order:
+    assert scorer.lstm_variant == "gemv"           # matrix-vector kernel, same accumulation order:
     assert np.array_equal(one.view(np.uint32), q[:1].view(np.uint32))     # bit-identical to the MFMA kernel
     for bsz in (2, 3, 4):
         few = scorer.q_predict(S[10:10 + bsz])
-        assert scorer.lstm_variant == "h128-gemv"
+        assert scorer.lstm_variant == "gemv"
         assert np.array_equal(few.view(np.uint32), q[10:10 + bsz].view(np.uint32))
     assert np.array_equal(scorer.q_predict(S[:5]).view(np.uint32), q[:5].view(np.uint32)) and scorer.lstm_variant == "h128i2"
     # the same states scored as sliding windows of the series give the same bits
@@ -239,6 +239,22 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     q64 = scorer.q_predict(S[:64])
     assert scorer.lstm_variant == "generic"
     assert_q_close(q64, orc.lstm_q(S[:64], lstm64["kernel"], lstm64["bias"], lstm64["w_out"], lstm64["b_out"], dtype=np.float64))
+    two = scorer.q_predict(S[5:7])
+    assert scorer.lstm_variant == "gemv" and np.array_equal(two.view(np.uint32), q64[5:7].view(np.uint32))
+    # multivariate explicit states (the WaDi driver's ql.predict(s0), ql.predict(s1): myasp-wadi.py:326-328)
+    for F_, H_ in ((123, 64), (38, 128), (5, 104)):
+        lm = synth_lstm(rng, F_ + 1, H_)
+        lm["kernel"][:F_] *= 0.05
+        scorer.set_lstm(lm)
+        st = rng.normal(size=(40, W, F_ + 1)).astype(np.float32)
+        st[:, :, F_] = (st[:, :, F_] > 0)
+        qg = scorer.q_predict(st)
+        assert scorer.lstm_variant == "generic"
+        assert_q_close(qg, orc.lstm_q(st, lm["kernel"], lm["bias"], lm["w_out"], lm["b_out"], dtype=np.float64))
+        for lo, n in ((0, 1), (7, 2), (20, 4)):
+            qs = scorer.q_predict(st[lo:lo + n])
+            assert scorer.lstm_variant == "gemv"
+            assert np.array_equal(qs.view(np.uint32), qg[lo:lo + n].view(np.uint32)), (F_, H_, lo, n)
     scorer.set_lstm(lstm)
     X = orc.vae_windows_univariate(v, W)[:100]
     rec, err = scorer.vae_predict(X, return_err=True)
