@@ -73,6 +73,7 @@ struct drl_ctx {
     void* rccl_lib = nullptr;
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_size = 0;
+    bool force_generic = false;   // DRLVAE_FORCE_GENERIC=1: explicit-state batches always take the fallback kernel (tests)
     int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
     bool last_overlap = false;
     std::string err;
@@ -336,6 +337,7 @@ int drl_create(int device_id, drl_ctx** out) {
         c->overlap_mode = 0;                    // degrade to one stream, never fail creation for it
         c->aux_stream = nullptr;
     }
+    if (const char* e = getenv("DRLVAE_FORCE_GENERIC")) c->force_generic = atoi(e) != 0;
     if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
     *out = c;
     return DRL_OK;
@@ -746,7 +748,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128), 2), dim3(256), 0, c->stream, xa);
             RecArgs ra;
-            ra.P = xa.P; ra.n_samples = n_samples;
+            ra.P = xa.P; ra.n_samples = n_samples; ra.win_rows = 1;
             ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
             if (sh.tiles32 * a.S <= c->n_cu) {
                 a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
@@ -780,7 +782,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
             RecArgs ra;
             a.n_tiles = sh.tiles32;
-            ra.l = a; ra.P = xa.P; ra.n_samples = n_samples;
+            ra.l = a; ra.P = xa.P; ra.n_samples = n_samples; ra.win_rows = 1;
             ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
             // S == 2: a workgroup is 2 tiles x 2 candidates; S == 1: 4 tiles
             const unsigned rec_grid = a.S == 2 ? (sh.tiles32 + 1) / 2 : (sh.tiles32 + 3) / 4;
@@ -984,6 +986,43 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), 1), dim3(256), 0, c->stream, a);
         }
         c->last_variant = "h128i2";
+    } else if (!c->force_generic && (size_t)B * W * (c->lstm.NT == 8 ? 1024 : 2048) <= ((size_t)8 << 30)) {
+        // other shapes (e.g. a replay batch of WaDi states): every row of every state is projected once
+        // (the flag is just the last input column here), then the recurrence kernels of the sliding-window
+        // path run with W projected rows between consecutive "windows"
+        const long long n_rows = (long long)B * W;
+        const int NTl = c->lstm.NT;
+        if ((rc = ensure(c, c->pbuf, (size_t)n_rows * NTl * 32 * sizeof(float)))) return rc;
+        XprojArgs xa;
+        xa.x = a.x; xa.n_samples = n_rows; xa.F = I; xa.wx = a.wx; xa.bias = a.bias; xa.P = (float*)c->pbuf.p;
+        xa.nt_total = NTl; xa.samp_off = nullptr; xa.n_seg = 0; xa.in_scale = nullptr; xa.in_offset = nullptr;
+        hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_rows + 127) / 128), NTl / 8), dim3(256), 0, c->stream, xa);
+        RecArgs ra;
+        ra.P = xa.P; ra.n_samples = n_rows; ra.win_rows = W;
+        ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
+        a.flag_mode = 0;                                    // nothing synthesised
+        if (NTl == 8) {
+            const size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);
+            if (!c->rec_attr_set) {
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                c->rec_attr_set = true;
+            }
+            ra.l = a;
+            hipLaunchKernelGGL((lstm_rec_kernel<8, false>), dim3((sh.tiles32 + 3) / 4), dim3(256), lds, c->stream, ra);
+            c->last_variant = "xproj+rec";
+        } else if (sh.tiles32 <= c->n_cu) {
+            ra.l = a;
+            hipLaunchKernelGGL(lstm_h128p_kernel<1>, dim3(sh.tiles32, 1), dim3(256), 0, c->stream, ra);
+            c->last_variant = "xproj+h128";
+        } else {
+            a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+            ra.l = a;
+            hipLaunchKernelGGL(lstm_h128p_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), 1), dim3(256), 0, c->stream, ra);
+            c->last_variant = "xproj+h128";
+        }
     } else {
         if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
         else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);

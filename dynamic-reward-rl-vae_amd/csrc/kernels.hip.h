@@ -749,6 +749,8 @@ struct RecArgs {
     const float* P;          // xproj output
     long long n_samples;
     const float* flagw;      // packed [NT][2][16]: the flag row of Wx in accumulator order
+    int win_rows;            // projected rows between consecutive windows: 1 (sliding windows of a series) or
+                             // W (explicit estimator.predict states: every state brings its own W rows)
 };
 
 // 4 waves per workgroup (one per SIMD), each an independent 32-window x 1-candidate recurrence:
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
     const int count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
     const int jj = j < count ? j : count - 1;
     const long long k = k0 + jj;
-    const long long nrow0 = samp0 + a.row0 + k;            // sample of row 0 of this lane's window
+    const long long nrow0 = samp0 + a.row0 + k * ra.win_rows;   // projected row of row 0 of this lane's window
     const float* __restrict__ ul = rec_u + lane;
     // one chunk of P is n_samples*32 bytes (< 4 GiB, checked by the host): 32-bit lane offsets
     // against 4*NT uniform chunk bases
@@ -1191,7 +1193,7 @@ __global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
             int jw = g * 32 + j;
             if (jw > count - 1) jw = count - 1;
             kw[g] = k0 + jw;
-            nrow[g] = sg.samp0 + a.row0 + kw[g];
+            nrow[g] = sg.samp0 + a.row0 + kw[g] * ra.win_rows;
             voff[g] = (unsigned)((size_t)nrow[g] * 32 + half * 16);
         }
         // projections of row t of group g into the accumulators of this wave's four gate tiles

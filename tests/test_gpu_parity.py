@@ -203,6 +203,25 @@ def test_edge_cases_ragged_short_series(scorer, ckpt_a1):
 
 
 # ----------------------------------------------------------------------------------- call surface
+_fallback = []
+
+
+def _fallback_scorer():
+    """A second context created with DRLVAE_FORCE_GENERIC=1 (read at drl_create)."""
+    if not _fallback:
+        from drlvae.scorer import WindowScorer
+        old = os.environ.get("DRLVAE_FORCE_GENERIC")
+        os.environ["DRLVAE_FORCE_GENERIC"] = "1"
+        try:
+            _fallback.append(WindowScorer(0))
+        finally:
+            if old is None:
+                del os.environ["DRLVAE_FORCE_GENERIC"]
+            else:
+                os.environ["DRLVAE_FORCE_GENERIC"] = old
+    return _fallback[0]
+
+
 def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     lstm, vae = ckpt_a1
     scorer.set_vae(vae)
@@ -237,7 +256,7 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     lstm64 = synth_lstm(rng, 2, 64)
     scorer.set_lstm(lstm64)
     q64 = scorer.q_predict(S[:64])
-    assert scorer.lstm_variant == "generic"
+    assert scorer.lstm_variant == "xproj+rec"
     assert_q_close(q64, orc.lstm_q(S[:64], lstm64["kernel"], lstm64["bias"], lstm64["w_out"], lstm64["b_out"], dtype=np.float64))
     two = scorer.q_predict(S[5:7])
     assert scorer.lstm_variant == "gemv" and np.array_equal(two.view(np.uint32), q64[5:7].view(np.uint32))
@@ -249,8 +268,12 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
         st = rng.normal(size=(40, W, F_ + 1)).astype(np.float32)
         st[:, :, F_] = (st[:, :, F_] > 0)
         qg = scorer.q_predict(st)
-        assert scorer.lstm_variant == "generic"
+        assert scorer.lstm_variant == ("xproj+rec" if H_ <= 64 else "xproj+h128")
         assert_q_close(qg, orc.lstm_q(st, lm["kernel"], lm["bias"], lm["w_out"], lm["b_out"], dtype=np.float64))
+        fb = _fallback_scorer()
+        fb.set_lstm(lm)
+        qf = fb.q_predict(st)                           # the fallback kernel (whole cell per wave, weights from L2)
+        assert fb.lstm_variant == "generic" and np.array_equal(qf.view(np.uint32), qg.view(np.uint32))
         for lo, n in ((0, 1), (7, 2), (20, 4)):
             qs = scorer.q_predict(st[lo:lo + n])
             assert scorer.lstm_variant == "gemv"
