@@ -222,6 +222,8 @@ def main():
     rehearse = os.environ.get("DRLVAE_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
+    else:
+        local %= max(1, torch.cuda.device_count())        # a launcher may expose one device per rank
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if rehearse else dev  # gloo has no GPU all_gather: the rehearsal stages through the host
