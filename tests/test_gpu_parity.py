@@ -524,6 +524,18 @@ def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckp
         prf = orc.precision_recall_f1(a1["anomaly"][idx][W:], a)
         exact += prf == pytest.approx(tuple(want_perf), abs=1e-9)
     assert exact >= 4
+    # a third committed run (A1 LP200/AL10000): 5 of 6 episodes of its performance file
+    kx = json.load(open(os.path.join(GOLDEN, "soft_kat_extra.json")))["a1_al10000"]
+    lx, _ = load_model_npz("ckpt_a1_al10000.npz")
+    scorer.set_lstm(lx)
+    exact = 0
+    for jx, want_perf in enumerate(kx["perf"]):
+        idx = kx["first_index"] + jx
+        a = scorer.rollout(a1["series"][idx], W)
+        prf = orc.precision_recall_f1(a1["anomaly"][idx][W:], a)
+        exact += prf == pytest.approx(tuple(want_perf), abs=1e-9)
+    assert exact >= 5
+    scorer.set_lstm(lstm)
     # device-side MinMax in the rollout: raw values + (scale, offset) give the same actions
     raw = a1["raw3"][0]
     sc, of = orc.minmax_f32(raw)[1:]

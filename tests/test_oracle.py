@@ -112,3 +112,23 @@ def test_survey_appendix_c_anchors(a1, ckpt_a1):
         == (0.08446, 0.16817, 0.2089)
     np.testing.assert_allclose(out["q"][:3], [[30.0847, 28.5161], [30.1293, 28.4941], [30.2094, 28.6030]], atol=6e-5)
     assert int(out["action"].sum()) == 1 and len(out["action"]) == 1395
+
+
+def test_soft_kat_a1_al10000(a1):
+    """A third committed run (A1 LP200/AL10000, tests/golden/make_extra_kat.py): 5 of its 6 validation
+    episodes are reproduced exactly, the sixth within two predicted positives."""
+    kat = json.load(open(os.path.join(GOLDEN, "soft_kat_extra.json")))["a1_al10000"]
+    lstm, _ = load_model_npz("ckpt_a1_al10000.npz")
+    exact = 0
+    for j, want in enumerate(kat["perf"]):
+        idx = kat["first_index"] + j
+        assert a1["names"][idx] == kat["files"][j]
+        truth = a1["anomaly"][idx]
+        (p, r, f), npos = _rollout_prf(a1["series"][idx], truth, lstm)
+        if (p, r, f) == pytest.approx(tuple(want), abs=1e-9):
+            exact += 1
+        else:
+            tp_ref = round(want[1] * int(truth[W:].sum()))
+            npos_ref = round(tp_ref / want[0]) if want[0] else 0
+            assert abs(npos - npos_ref) <= 2, (j, npos, npos_ref)
+    assert exact >= 5
