@@ -145,3 +145,23 @@ def test_dynamic_coef_update_matches_reference_formula():
     assert upd(1.0, -500.0, target_reward=0.0, alpha=0.001) == pytest.approx(1.5)
     assert upd(1.0, 2000.0, target_reward=0.0, alpha=0.001) == 0.1
     assert upd(9.9, -5000.0, target_reward=0.0, alpha=0.001) == 10.0
+
+
+@pytest.mark.parametrize("fname,shapes,acts,clip", [
+    ("vae_model.h5", [(25, 64), (64, 64), (64, 10), (64, 10), (10, 64), (64, 25)], [1, 1, 0, 0, 1, 2], 10.0),
+    ("vae_model_kpi.h5", [(1, 16), (16, 16), (16, 2), (16, 2), (2, 16), (16, 16), (16, 1)], [1, 1, 0, 0, 1, 1, 0], float("inf")),
+])
+def test_keras_hdf5_reader_on_the_reference_files(fname, shapes, acts, clip):
+    """Both Keras files the reference ships (Keras 2.13.1 and 2.10.0), read without h5py: layer order,
+    which Dense is mu / logvar (from the sampling layer's inbound nodes), activations, the logvar clip.
+    Needs the reference tree, which exists in the build container only."""
+    path = os.path.join("/root/reference", fname)
+    if not os.path.exists(path):
+        pytest.skip("the reference tree is not mounted here")
+    from drlvae.formats.keras_h5 import load_keras_vae
+    v = load_keras_vae(path)
+    assert [k.shape for k in v["kernels"]] == shapes
+    assert [b.shape for b in v["biases"]] == [(s[1],) for s in shapes]
+    assert list(v["acts"]) == acts and (v["mu_layer"], v["logvar_layer"]) == (2, 3)
+    assert v["logvar_clip"] == clip
+    assert all(np.isfinite(k).all() for k in v["kernels"])
