@@ -165,3 +165,31 @@ def test_keras_hdf5_reader_on_the_reference_files(fname, shapes, acts, clip):
     assert list(v["acts"]) == acts and (v["mu_layer"], v["logvar_layer"]) == (2, 3)
     assert v["logvar_clip"] == clip
     assert all(np.isfinite(k).all() for k in v["kernels"])
+
+
+def test_tf_bundle_reader_on_every_reference_checkpoint():
+    """Every TF1 Saver bundle the reference ships (20 runs; two naming schemes of the VAE layers,
+    Q-net-only bundles, the I = 1 AdaptiveTauRL net): found, CRC32C-verified, shapes consistent.
+    Needs the reference tree, which exists in the build container only."""
+    import glob
+    idx = sorted(set(glob.glob("/root/reference/exp*/**/model.index", recursive=True)))
+    if not idx:
+        pytest.skip("the reference tree is not mounted here")
+    from drlvae.formats.tf_bundle import TFBundle, load_q_estimator, load_vae_dense_chain
+    assert len(idx) >= 19
+    with_vae = 0
+    for path in idx:
+        prefix = path[:-len(".index")]
+        lstm = load_q_estimator(prefix, "qlearn")
+        k = lstm["kernel"]
+        H = k.shape[1] // 4
+        assert k.shape[0] - H in (1, 2) and lstm["bias"].shape == (4 * H,) and lstm["w_out"].shape == (H, 2)
+        b = TFBundle(prefix)
+        for name in b.names():
+            if name.endswith("lstm_cell/kernel"):
+                b.get(name, verify_crc=True)
+        chain = load_vae_dense_chain(prefix)
+        if chain is not None:
+            with_vae += 1
+            assert [kk.shape for kk, _ in chain] == [(25, 64), (64, 64), (64, 64), (64, 10), (64, 10), (10, 64), (64, 25)]
+    assert with_vae >= 17
