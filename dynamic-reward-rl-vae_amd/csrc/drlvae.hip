@@ -641,7 +641,12 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
     }
     if (want_q) {
         if (!c->lstm.set) return fail(c, DRL_ERR_STATE, "Q requested but drl_set_lstm was not called");
-        if (c->lstm.I != F + 1) return fail(c, DRL_ERR_ARG, "LSTM in_dim %d != F+1 = %d", c->lstm.I, F + 1);
+        // in_dim == F: a network without the flag channel (the reference's legacy RLVAL / AdaptiveTauRL
+        // estimators take the value alone); only DRL_FLAG_ZEROS makes sense there
+        if (c->lstm.I == F && o->flag_mode != DRL_FLAG_ZEROS)
+            return fail(c, DRL_ERR_ARG, "LSTM in_dim %d == F: the network has no flag channel, use DRL_FLAG_ZEROS", c->lstm.I);
+        if (c->lstm.I != F + 1 && c->lstm.I != F)
+            return fail(c, DRL_ERR_ARG, "LSTM in_dim %d != F+1 = %d (or F, for a network without the flag channel)", c->lstm.I, F + 1);
         if (!d_q) return fail(c, DRL_ERR_ARG, "action/margin need the q output buffer");
     }
     SegHost sh;

@@ -112,7 +112,9 @@ int drl_set_vae(drl_ctx* ctx, int n_layers, const int32_t* in_dims, const int32_
 /* Replaces Q_Estimator_Nonlinear.__init__ + Saver.restore (reference myasp-A1.py:165-179,
  * 313-319) / QNet.build (myasp-wadi.py:212-224): TF1 LSTMCell(hidden, forget_bias) under
  * static_rnn with zero initial state, kernel [in_dim+hidden, 4*hidden] with gate column blocks
- * i|j|f|o, followed by Q = h_T.w_out + b_out. */
+ * i|j|f|o, followed by Q = h_T.w_out + b_out.  in_dim = F + 1 (features + the action flag); a network
+ * without the flag channel (in_dim = F: the legacy RLVAL / AdaptiveTauRL estimators) is scored with
+ * DRL_FLAG_ZEROS. */
 int drl_set_lstm(drl_ctx* ctx, int in_dim, int hidden, int n_actions, float forget_bias,
                  const float* kernel, const float* bias, const float* w_out, const float* b_out);
 

@@ -209,3 +209,19 @@ def test_repeated_calls_are_bit_identical():
                     assert np.array_equal(first[key].view(np.uint32), again[key].view(np.uint32)), (name, key, rep)
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("F,H", [(1, 128), (3, 64), (1, 64)])
+def test_network_without_flag_channel(scorer, F, H):
+    """in_dim == F: the reference's legacy estimators (AdaptiveTauRL: kernel [129, 512]) see the values only."""
+    rng = np.random.default_rng(900 + F + H)
+    Wn, N = 25, 400
+    x = rng.random((N, F), dtype=np.float32)
+    lstm = synth_lstm(rng, F, H)
+    scorer.set_lstm(lstm)
+    out = scorer.score(x if F > 1 else x[:, 0], Wn, vae_lag=0, flag_mode="zeros", want=("q", "action"))
+    idx = np.arange(N - Wn)[:, None] + 1 + np.arange(Wn)[None, :]
+    want = orc.lstm_q(x[idx], lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float64)
+    assert _nrel(out["q"], want) <= RTOL
+    with pytest.raises(RuntimeError, match="no flag channel"):
+        scorer.score(x if F > 1 else x[:, 0], Wn, vae_lag=0, flag_mode="quirk", want=("q",))
