@@ -225,3 +225,22 @@ def test_network_without_flag_channel(scorer, F, H):
     assert _nrel(out["q"], want) <= RTOL
     with pytest.raises(RuntimeError, match="no flag channel"):
         scorer.score(x if F > 1 else x[:, 0], Wn, vae_lag=0, flag_mode="quirk", want=("q",))
+
+
+@pytest.mark.parametrize("F,last_act", [(1, 0), (1, 1), (8, 0), (8, 1), (8, 2)])
+def test_vae_output_activations(scorer, F, last_act):
+    """Linear / relu / sigmoid output layers (the reference's KPI VAE ends in a linear Dense), on the
+    chain kernel (D = 25) and on the wide kernel (D = 200)."""
+    rng = np.random.default_rng(50 + F * 3 + last_act)
+    Wn, N = 25, 500
+    D = Wn * F
+    vae = synth_vae(rng, [D, 128, 10, 128, D], 1)
+    vae["acts"][-1] = last_act
+    x = rng.random((N, F), dtype=np.float32)
+    scorer.set_vae(vae)
+    out = scorer.score(x if F > 1 else x[:, 0], Wn, vae_lag=0, want=("err",))
+    idx = np.arange(N - Wn)[:, None] + 1 + np.arange(Wn)[None, :]
+    X = x[idx].reshape(N - Wn, D)
+    rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], 10.0,
+                          dtype=np.float64)
+    np.testing.assert_allclose(out["err"], orc.recon_error(X, rec, dtype=np.float64), rtol=RTOL)
