@@ -244,3 +244,46 @@ def test_vae_output_activations(scorer, F, last_act):
     rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], 10.0,
                           dtype=np.float64)
     np.testing.assert_allclose(out["err"], orc.recon_error(X, rec, dtype=np.float64), rtol=RTOL)
+
+
+def test_many_short_series_and_a_very_wide_one(scorer):
+    """20,000 series of 10..200 samples (most of the segment-table lookups leave the LDS copy: more
+    than 512 series) and a 300-feature stream whose windows (D = 7,500) are too wide for the LDS-staged
+    VAE kernel: spot-checked against the oracle, and against single-series calls bit for bit."""
+    rng = np.random.default_rng(2024)
+    vae, _, _ = _rand_vae(rng, 25)
+    lstm = synth_lstm(rng, 2, 128)
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    lens = rng.integers(10, 201, 20000)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    x = rng.random(int(off[-1]), dtype=np.float32)
+    out = scorer.score(x, 25, off, flag_mode="quirk")
+    kcount = np.maximum(lens - 25, 0)
+    woff = np.concatenate([[0], np.cumsum(kcount)])
+    assert len(out["err"]) == woff[-1]
+    for i in (0, 1, 777, 5000, 12345, 19999):
+        k = int(kcount[i])
+        if k == 0:
+            continue
+        v = x[off[i]:off[i + 1]]
+        one = scorer.score(v, 25, flag_mode="quirk")
+        for key in out:
+            assert np.array_equal(one[key].view(np.uint32), out[key][woff[i]:woff[i] + k].view(np.uint32)), (i, key)
+        want = orc.score_series_univariate(v, 25, vae, lstm, "quirk", dtype=np.float64)
+        np.testing.assert_allclose(one["err"], want["err"], rtol=RTOL)
+        # these random heads put Q near zero (a sum of 128 terms of size ~0.5 cancelling to ~0.1), so the
+        # error is measured against the series' largest |Q|, not window by window
+        assert np.abs(one["q"] - want["q"]).max() / np.abs(want["q"]).max() <= RTOL
+    # very wide windows
+    F, N = 300, 700
+    xm = rng.random((N, F), dtype=np.float32)
+    vae_w = synth_vae(rng, [25 * F, 128, 10, 128, 25 * F], 1)
+    lstm_w = synth_lstm(rng, F + 1, 64)
+    lstm_w["kernel"][:F] *= 0.2
+    scorer.set_vae(vae_w)
+    scorer.set_lstm(lstm_w)
+    got = scorer.score(xm, 25, vae_lag=0, flag_mode="both", action_rule="wadi")
+    want = orc.score_series_multivariate(xm, 25, vae_w, lstm_w, None, None, 10.0, dtype=np.float64)
+    np.testing.assert_allclose(got["err"], want["err"], rtol=RTOL)
+    assert _nrel(got["q"], want["q"]) <= RTOL
