@@ -10,6 +10,20 @@
 // (k-step r of an input tile pairs rows rowmap(r,0) and rowmap(r,1)), so activations chain from
 // layer to layer, and h_t feeds step t+1, without leaving the register file; the weights are
 // packed on the host in exactly that k order (pack_* in drlvae.hip).
+//
+// Kernels, in file order (DESIGN.md section 4 has the table with shapes and bounds):
+//   vae_kernel<MAXT>            VAE chain, narrow windows / explicit batches / eps path
+//   vae_wide_kernel<SCALED>     VAE, wide windows: LDS-staged windows, weights through an LDS ring
+//   lstm_generic_kernel<NT>     fallback LSTM (whole cell per wave, weights from L2)
+//   xproj_kernel<NT>            input projections once per sample
+//   lstm_rec_kernel<NT,FLAGGED> recurrence from the projections, H <= 64
+//   lstm_h128i2_kernel<NG>      univariate H <= 128: U stationary in registers, persistent grid
+//   lstm_h128p_kernel<NG>       the same fed from projections (any input width)
+//   lstm_gemv_kernel<NT>        estimator.predict at batch 1..4 (VALU matrix-vector)
+//   finalize_kernel, rollout_*_kernel, al_*_kernel   per-window epilogues
+// lstm_f16x3.hip.h adds the opt-in 3-term f16-split variant of lstm_h128i2_kernel.
+// VW_ABL / H128_ABL are timing-only ablation switches (wrong results) used to price the parts of a
+// kernel; the default build has them off.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
