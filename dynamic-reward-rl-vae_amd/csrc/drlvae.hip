@@ -3,6 +3,7 @@
 #include "../../include/drlvae.h"
 #include "kernels.hip.h"
 #include "lstm_f16x3.hip.h"
+#include "lstm_w16.hip.h"
 
 #include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
@@ -46,6 +47,8 @@ struct LstmHost {
     size_t wx_off = 0, u_off = 0, bias_off = 0, wout_off = 0, bout_off = 0, flagw_off = 0;
     size_t uhi_off = 0, ulo_off = 0;      // f16 hi/lo split of U (H = 128 only), float offsets, 16-B aligned
     bool has_split = false;
+    size_t u16_off = 0, wx16_off = 0, bias16_off = 0;   // 16-window-tile layout (I = 2, H > 64)
+    bool has16 = false;
 };
 
 struct Prof {
@@ -98,7 +101,7 @@ struct drl_ctx {
     // the segment tables of the last call stay valid on the device while the same series layout is scored again
     std::vector<int64_t> seg_key;
     long long seg_K = 0;
-    int seg_t32 = 0, seg_t64 = 0;
+    int seg_t32 = 0, seg_t64 = 0, seg_t16 = 0;
 };
 
 namespace {
@@ -204,28 +207,30 @@ int prof_collect(drl_ctx* c) {
 
 struct SegHost {
     long long K_total = 0;
-    int tiles32 = 0, tiles64 = 0;
+    int tiles32 = 0, tiles64 = 0, tiles16 = 0;
     // device pointers into ctx->seg
     const long long* d_samp = nullptr;
     const long long* d_win = nullptr;
     const int* d_t32 = nullptr;
     const int* d_t64 = nullptr;
+    const int* d_t16 = nullptr;
 };
 
 // Builds and uploads the per-series tables.  n_win[i] = windows of series i.
 int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, bool windows_are_rows,
                    SegHost& out) {
     const size_t n1 = (size_t)n_seg + 1;
-    const size_t bytes = n1 * (2 * sizeof(long long) + 2 * sizeof(int));
+    const size_t bytes = n1 * (2 * sizeof(long long) + 3 * sizeof(int));
     std::vector<int64_t> key(seg_offsets, seg_offsets + n1);
     key.push_back(W);
     key.push_back(windows_are_rows ? 1 : 0);
     if (key == c->seg_key && c->seg.p) {
-        out.K_total = c->seg_K; out.tiles32 = c->seg_t32; out.tiles64 = c->seg_t64;
+        out.K_total = c->seg_K; out.tiles32 = c->seg_t32; out.tiles64 = c->seg_t64; out.tiles16 = c->seg_t16;
         out.d_samp = (const long long*)c->seg.p;
         out.d_win = out.d_samp + n1;
         out.d_t32 = (const int*)(out.d_win + n1);
         out.d_t64 = out.d_t32 + n1;
+        out.d_t16 = out.d_t64 + n1;
         return DRL_OK;
     }
     c->seg_key.clear();
@@ -239,7 +244,8 @@ int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, boo
     long long* win = samp + n1;
     int* t32 = (int*)(win + n1);
     int* t64 = t32 + n1;
-    long long wacc = 0, a32 = 0, a64 = 0;
+    int* t16 = t64 + n1;
+    long long wacc = 0, a32 = 0, a64 = 0, a16 = 0;
     for (int i = 0; i < n_seg; ++i) {
         const long long N = seg_offsets[i + 1] - seg_offsets[i];
         if (N < 0) return fail(c, DRL_ERR_ARG, "seg_offsets must be non-decreasing (series %d)", i);
@@ -248,24 +254,29 @@ int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, boo
         win[i] = wacc;
         t32[i] = (int)a32;
         t64[i] = (int)a64;
+        t16[i] = (int)a16;
         wacc += K;
         a32 += (K + 31) / 32;
         a64 += (K + 63) / 64;
-        if (a32 > 0x7fffffffLL) return fail(c, DRL_ERR_ARG, "too many windows for one call");
+        a16 += (K + 15) / 16;
+        if (a16 > 0x7fffffffLL) return fail(c, DRL_ERR_ARG, "too many windows for one call");
     }
     samp[n_seg] = seg_offsets[n_seg];
     win[n_seg] = wacc;
     t32[n_seg] = (int)a32;
     t64[n_seg] = (int)a64;
+    t16[n_seg] = (int)a16;
     HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
     out.K_total = wacc;
     out.tiles32 = (int)a32;
     out.tiles64 = (int)a64;
+    out.tiles16 = (int)a16;
     out.d_samp = (const long long*)c->seg.p;
     out.d_win = out.d_samp + n1;
     out.d_t32 = (const int*)(out.d_win + n1);
     out.d_t64 = out.d_t32 + n1;
-    c->seg_key = key; c->seg_K = wacc; c->seg_t32 = out.tiles32; c->seg_t64 = out.tiles64;
+    out.d_t16 = out.d_t64 + n1;
+    c->seg_key = key; c->seg_K = wacc; c->seg_t32 = out.tiles32; c->seg_t64 = out.tiles64; c->seg_t16 = out.tiles16;
     return DRL_OK;
 }
 
@@ -490,6 +501,13 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
         l.uhi_off = off; off += (size_t)16 * 8 * 64 * 4;     // [16 tiles][8 k-steps][64 lanes] x 8 f16 = 4 floats
         l.ulo_off = off; off += (size_t)16 * 8 * 64 * 4;
     }
+    l.has16 = (in_dim == 2 && hidden > 64);
+    if (l.has16) {
+        off = up16(off);
+        l.u16_off = off; off += (size_t)32 * 32 * 64;
+        l.wx16_off = off; off += (size_t)32 * 64;
+        l.bias16_off = off; off += (size_t)32 * 16;
+    }
     std::vector<float> pack(off, 0.0f);
     // gate-interleaved rows: row i of tile tau = (unit 8*tau + (i>>2), gate i&3) -> TF column gate*H + unit
     auto col = [&](int tau, int i) -> int {
@@ -542,6 +560,34 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
                         hi[o] = h16;
                         lo[o] = (_Float16)(wv - (float)h16);
                     }
+    }
+    if (l.has16) {
+        // 16-window-tile layout (lstm_w16.hip.h): tile T row i = (unit 4T + (i>>2), gate i&3)
+        auto col16 = [&](int T, int i) -> int {
+            const int unit = 4 * T + (i >> 2), gate = i & 3;
+            return unit < H ? gate * H + unit : -1;
+        };
+        for (int kk = 0; kk < 32; ++kk)
+            for (int T = 0; T < 32; ++T)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int i = ln & 15, u = 4 * kk + (ln >> 4), cc = col16(T, i);
+                    pack[l.u16_off + ((size_t)kk * 32 + T) * 64 + ln] =
+                        (u < H && cc >= 0) ? (float)(gscale(i) * kernel[(size_t)(in_dim + u) * ld + cc]) : 0.0f;
+                }
+        for (int T = 0; T < 32; ++T)
+            for (int ln = 0; ln < 64; ++ln) {
+                const int i = ln & 15, feat = ln >> 4, cc = col16(T, i);
+                pack[l.wx16_off + (size_t)T * 64 + ln] =
+                    (feat < in_dim && cc >= 0) ? (float)(gscale(i) * kernel[(size_t)feat * ld + cc]) : 0.0f;
+            }
+        for (int T = 0; T < 32; ++T)
+            for (int qq = 0; qq < 4; ++qq)
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 4 * qq + r, cc = col16(T, i);
+                    const double fbias = r == 2 ? (double)forget_bias : 0.0;
+                    pack[l.bias16_off + ((size_t)T * 4 + qq) * 4 + r] =
+                        cc >= 0 ? (float)(gscale(i) * ((double)bias[cc] + fbias)) : 0.0f;
+                }
     }
     // the flag row of Wx (last input feature) in accumulator order, for the x-projection path
     for (int tau = 0; tau < NT; ++tau)
@@ -730,6 +776,16 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.ulo = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.ulo_off);
             hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
             c->last_variant = "h128i2_f16x3";
+        } else if (fast && c->lstm.has16 && sh.tiles16 * a.S <= c->n_cu) {
+            // a call of a few thousand windows (one series): 16-window tiles, twice as many workgroups again
+            a.seg.tile_off = sh.d_t16; a.n_tiles = sh.tiles16;
+            Lstm16Args fa;
+            fa.l = a;
+            fa.u16 = (const float*)c->lstm_w.p + c->lstm.u16_off;
+            fa.wx16 = (const float*)c->lstm_w.p + c->lstm.wx16_off;
+            fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
+            hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(sh.tiles16, a.S), dim3(256), 0, c->stream, fa);
+            c->last_variant = "h128i2";
         } else if (fast && sh.tiles32 <= c->n_cu) {
             // a small call (one series, a replay batch): 32-window tiles over twice as many CUs
             a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
@@ -984,7 +1040,15 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
         c->last_variant = "gemv";
     } else if (I == 2 && c->lstm.NT == 16 && W >= 2) {
         // the register-stationary univariate kernel, reading the states row by row
-        if (sh.tiles32 <= c->n_cu) {
+        if (c->lstm.has16 && sh.tiles16 <= c->n_cu) {
+            a.seg.tile_off = sh.d_t16; a.n_tiles = sh.tiles16;
+            Lstm16Args fa;
+            fa.l = a;
+            fa.u16 = (const float*)c->lstm_w.p + c->lstm.u16_off;
+            fa.wx16 = (const float*)c->lstm_w.p + c->lstm.wx16_off;
+            fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
+            hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(sh.tiles16, 1), dim3(256), 0, c->stream, fa);
+        } else if (sh.tiles32 <= c->n_cu) {
             hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, 1), dim3(256), 0, c->stream, a);
         } else {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
