@@ -96,6 +96,7 @@ struct drl_ctx {
     size_t pinned_cap = 0;
     Prof prof;
     const char* last_variant = "none";
+    int last_tile = 0;   // windows per workgroup tile of the last LSTM launch (0: not a tiled kernel)
     const char* last_vae_variant = "none";
     size_t wide_lds_set = 0, gemv_lds_set = 0;
     // the segment tables of the last call stay valid on the device while the same series layout is scored again
@@ -767,6 +768,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.q = d_q;
         // hidden widths 65..128 are packed zero-padded to 16 gate tiles x 64 k-steps (padded units stay at h = 0)
         const bool fast = c->lstm.I == 2 && c->lstm.NT == 16 && F == 1 && W >= 2 && W + 65 <= H128_SV;
+        c->last_tile = 0;
         prof_begin(c, 0, c->stream);
         if (fast && c->lstm_math == 1 && c->lstm.has_split) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
@@ -775,7 +777,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.uhi = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.uhi_off);
             fa.ulo = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.ulo_off);
             hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
-            c->last_variant = "h128i2_f16x3";
+            c->last_variant = "h128i2_f16x3"; c->last_tile = 64;
         } else if (fast && c->lstm.has16 && sh.tiles16 * a.S <= c->n_cu) {
             // a call of a few thousand windows (one series): 16-window tiles, twice as many workgroups again
             a.seg.tile_off = sh.d_t16; a.n_tiles = sh.tiles16;
@@ -785,17 +787,17 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.wx16 = (const float*)c->lstm_w.p + c->lstm.wx16_off;
             fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
             hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(sh.tiles16, a.S), dim3(256), 0, c->stream, fa);
-            c->last_variant = "h128i2";
+            c->last_variant = "h128i2"; c->last_tile = 16;
         } else if (fast && sh.tiles32 <= c->n_cu) {
             // a small call (one series, a replay batch): 32-window tiles over twice as many CUs
             a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
             hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, a);
-            c->last_variant = "h128i2";
+            c->last_variant = "h128i2"; c->last_tile = 32;
         } else if (fast) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
-            c->last_variant = "h128i2";
+            c->last_variant = "h128i2"; c->last_tile = 64;
         } else if (c->lstm.NT == 16 &&
                    (size_t)seg_offsets[n_seg] * 2048 <= ((size_t)64 << 30)) {   // projections: 2 KiB per sample
             // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
@@ -1023,6 +1025,7 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     a.n_tiles = sh.tiles32; a.S = 1; a.q = (float*)c->st_q.p;
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
+    c->last_tile = 0;
     prof_begin(c, 0, c->stream);
     const int gv_rows = 32 * c->lstm.NT, gv_ip = (I + 3) & ~3;
     const size_t gv_lds = ((size_t)W * gv_ip + (size_t)W * gv_rows) * sizeof(float);
@@ -1048,11 +1051,14 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
             fa.wx16 = (const float*)c->lstm_w.p + c->lstm.wx16_off;
             fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
             hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(sh.tiles16, 1), dim3(256), 0, c->stream, fa);
+            c->last_tile = 16;
         } else if (sh.tiles32 <= c->n_cu) {
             hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, 1), dim3(256), 0, c->stream, a);
+            c->last_tile = 32;
         } else {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), 1), dim3(256), 0, c->stream, a);
+            c->last_tile = 64;
         }
         c->last_variant = "h128i2";
     } else if (!c->force_generic && (size_t)B * W * (c->lstm.NT == 8 ? 1024 : 2048) <= ((size_t)8 << 30)) {
@@ -1254,6 +1260,7 @@ int drl_profile_read(drl_ctx* c, int which, double* total_ms, int64_t* launches)
     return DRL_OK;
 }
 const char* drl_last_lstm_variant(drl_ctx* c) { return c ? c->last_variant : "none"; }
+int drl_last_lstm_tile(drl_ctx* c) { return c ? c->last_tile : 0; }
 int drl_last_call_overlapped(drl_ctx* c) { return c && c->last_overlap ? 1 : 0; }
 
 /* ---- the path's only collective ------------------------------------------------------------------ */

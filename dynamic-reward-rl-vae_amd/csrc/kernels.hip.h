@@ -21,6 +21,8 @@
 //   lstm_h128p_kernel<NG>       the same fed from projections (any input width)
 //   lstm_gemv_kernel<NT>        estimator.predict at batch 1..4 (VALU matrix-vector)
 //   finalize_kernel, rollout_*_kernel, al_*_kernel   per-window epilogues
+// lstm_w16.hip.h adds lstm_h128i2_w16_kernel: the univariate recurrence on 16-window tiles
+// (v_mfma_f32_16x16x4_f32) for calls too small to fill the chip with 32-window tiles.
 // lstm_f16x3.hip.h adds the opt-in 3-term f16-split variant of lstm_h128i2_kernel.
 // VW_ABL / H128_ABL are timing-only ablation switches (wrong results) used to price the parts of a
 // kernel; the default build has them off.

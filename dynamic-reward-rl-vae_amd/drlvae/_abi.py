@@ -18,7 +18,7 @@ SYMBOLS = [
     "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
     "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
     "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
-    "drl_last_lstm_variant", "drl_last_call_overlapped",
+    "drl_last_lstm_variant", "drl_last_lstm_tile", "drl_last_call_overlapped",
     "drl_comm_unique_id", "drl_comm_init", "drl_allgather_scores", "drl_comm_destroy",
 ]
 
@@ -107,6 +107,8 @@ def load():
     lib.drl_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), _i64p]
     lib.drl_last_lstm_variant.argtypes = [vp]
     lib.drl_last_lstm_variant.restype = C.c_char_p
+    lib.drl_last_lstm_tile.argtypes = [vp]
+    lib.drl_last_lstm_tile.restype = C.c_int
     lib.drl_last_call_overlapped.argtypes = [vp]
     lib.drl_comm_unique_id.argtypes = [vp, vp]
     lib.drl_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]

@@ -301,6 +301,11 @@ class WindowScorer:
         return self._lib.drl_last_lstm_variant(self._h).decode()
 
     @property
+    def lstm_tile(self) -> int:
+        """Windows per workgroup tile of the last "h128i2" launch (16, 32 or 64), 0 otherwise."""
+        return int(self._lib.drl_last_lstm_tile(self._h))
+
+    @property
     def overlapped(self) -> bool:
         """True when the last scoring call ran its VAE kernel concurrently with the LSTM kernels."""
         return bool(self._lib.drl_last_call_overlapped(self._h))

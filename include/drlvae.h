@@ -220,6 +220,9 @@ int drl_profile_reset(drl_ctx* ctx);
 int drl_profile_read(drl_ctx* ctx, int which, double* total_ms, int64_t* launches);
 /* Name of the LSTM kernel variant the last scoring call used ("h128i2" or "generic"). */
 const char* drl_last_lstm_variant(drl_ctx* ctx);
+/* Windows per workgroup tile of that launch for the "h128i2" kernels (16, 32 or 64: chosen from the
+ * size of the call; results are bit-identical across the three), 0 for the other variants. */
+int drl_last_lstm_tile(drl_ctx* ctx);
 /* 1 when the last scoring call ran its VAE kernel on the library's second stream, concurrently with
  * the LSTM kernels (large wide-window calls; environment DRLVAE_OVERLAP = 0 never, 1 default,
  * 2 always).  Kernel durations read with drl_profile_read then overlap in time.  No counterpart in

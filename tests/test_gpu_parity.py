@@ -407,22 +407,34 @@ def test_shards_are_bit_identical_to_the_whole(scorer, a1, ckpt_a1):
 
 
 def test_small_calls_match_large_calls_bit_for_bit(scorer, a1, ckpt_a1):
-    """A call with few windows runs the univariate LSTM on 32-window tiles, a large one on 64-window
-    tiles (persistent grid): the same series must score identically, bit for bit, either way."""
+    """The univariate LSTM runs on 16-window tiles for a call of one series, on 32-window tiles for a
+    few series and on 64-window tiles (persistent grid) for a large call: the same series must score
+    identically, bit for bit, whichever kernel its call lands on."""
     lstm, vae = ckpt_a1
     scorer.set_vae(vae)
     scorer.set_lstm(lstm)
     series = a1["series"]
     off = np.concatenate([[0], np.cumsum([len(v) for v in series])]).astype(np.int64)
     big = scorer.score(np.concatenate(series), W, off, flag_mode="quirk")          # 93,191 windows
-    pos = 0
-    for i, v in enumerate(series):
-        k = len(v) - W
-        if i in (0, 7, 31, 66):
-            one = scorer.score(v, W, flag_mode="quirk")                             # ~1,400 windows
-            for key in big:
-                assert np.array_equal(one[key].view(np.uint32), big[key][pos:pos + k].view(np.uint32)), (i, key)
-        pos += k
+    assert scorer.lstm_tile == 64
+    wpos = np.concatenate([[0], np.cumsum([len(v) - W for v in series])])
+    for i in (0, 7, 31, 66):
+        one = scorer.score(series[i], W, flag_mode="quirk")                         # ~1,400 windows
+        assert scorer.lstm_tile == 16
+        for key in big:
+            assert np.array_equal(one[key].view(np.uint32), big[key][wpos[i]:wpos[i + 1]].view(np.uint32)), (i, key)
+    for i0 in (0, 40):
+        grp = series[i0:i0 + 5]                                                     # ~7,000 windows
+        goff = np.concatenate([[0], np.cumsum([len(v) for v in grp])]).astype(np.int64)
+        few = scorer.score(np.concatenate(grp), W, goff, flag_mode="quirk")
+        assert scorer.lstm_tile == 32
+        for key in big:
+            assert np.array_equal(few[key].view(np.uint32), big[key][wpos[i0]:wpos[i0 + 5]].view(np.uint32)), (i0, key)
+    both = scorer.score(series[3], W, flag_mode="both")                             # two flag states per window
+    assert scorer.lstm_tile == 16 and both["q"].shape == (len(series[3]) - W, 2, 2)
+    bigb = scorer.score(np.concatenate(series), W, off, flag_mode="both")
+    assert scorer.lstm_tile == 64
+    assert np.array_equal(both["q"].view(np.uint32), bigb["q"][wpos[3]:wpos[4]].view(np.uint32))
 
 
 def test_reference_call_surface_shims(scorer, a1, ckpt_a1):
