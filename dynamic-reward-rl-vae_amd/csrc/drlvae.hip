@@ -468,7 +468,7 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
         pack_bias(biases[logvar_layer], v.latent, pack.data() + v.blv_off, 1.0);
     }
     int rc = ensure(c, c->vae_w, off * sizeof(float));
-    if (rc) return rc;
+    if (rc) { c->vae.set = false; return rc; }      // the old pack may be gone: no stale weights
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->vae_w.p, pack.data(), off * sizeof(float), hipMemcpyHostToDevice));
     v.set = true;
@@ -602,7 +602,7 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
         for (int a = 0; a < n_actions; ++a) pack[l.wout_off + (size_t)u * n_actions + a] = w_out[(size_t)u * n_actions + a];
     for (int a = 0; a < n_actions; ++a) pack[l.bout_off + a] = b_out[a];
     int rc = ensure(c, c->lstm_w, off * sizeof(float));
-    if (rc) return rc;
+    if (rc) { c->lstm.set = false; return rc; }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->lstm_w.p, pack.data(), off * sizeof(float), hipMemcpyHostToDevice));
     l.set = true;
@@ -915,9 +915,7 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     const int S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
     const int A = c->lstm.set ? c->lstm.A : 2;
     const bool want_q = q || action || margin;
-    if ((action || margin) && !q) {
-        // the host entry point can stage q itself
-    }
+    // action/margin without q: the q block is staged on the device all the same (want_q)
     if ((rc = ensure(c, c->st_in, (size_t)total * F * sizeof(float)))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
     const float* d_flags = nullptr;
