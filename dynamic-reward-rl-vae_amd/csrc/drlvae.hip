@@ -78,6 +78,7 @@ struct drl_ctx {
     int comm_rank = 0, comm_size = 0;
     bool force_generic = false;   // DRLVAE_FORCE_GENERIC=1: explicit-state batches always take the fallback kernel (tests)
     int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
+    int rec2_mode = 1;            // two candidate states in one wave: 0 never, 1 whole rounds of tiles, 2 always (DRLVAE_REC2)
     bool last_overlap = false;
     std::string err;
     VaeHost vae;
@@ -351,6 +352,7 @@ int drl_create(int device_id, drl_ctx** out) {
     }
     if (const char* e = getenv("DRLVAE_FORCE_GENERIC")) c->force_generic = atoi(e) != 0;
     if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
+    if (const char* e = getenv("DRLVAE_REC2")) c->rec2_mode = atoi(e);
     *out = c;
     return DRL_OK;
 }
@@ -836,6 +838,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec2_kernel<8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 c->rec_attr_set = true;
             }
             XprojArgs xa;
@@ -847,9 +851,31 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             a.n_tiles = sh.tiles32;
             ra.l = a; ra.P = xa.P; ra.n_samples = n_samples; ra.win_rows = 1;
             ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
-            // S == 2: a workgroup is 2 tiles x 2 candidates; S == 1: 4 tiles
-            const unsigned rec_grid = a.S == 2 ? (sh.tiles32 + 1) / 2 : (sh.tiles32 + 3) / 4;
-            if (a.flag_mode > 0) hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
+            const unsigned rec_grid = (sh.tiles32 + 3) / 4;       // a workgroup is 4 waves, a wave one tile of 32 windows
+            if (a.S == 2) {
+                // Two candidate states.  lstm_rec2_kernel runs both in one wave (shared projections and weight
+                // fragments: ~5 % less time per window) but is twice as long per wave; lstm_rec_kernel gives
+                // each candidate its own wave.  With `slots` waves on the chip at a time, whole rounds of
+                // `slots` tiles go to the first, and a remainder that fits the chip as one wave per
+                // (tile, candidate) goes to the second — one round of half the length instead of a full one.
+                const int slots = 4 * c->n_cu;
+                const int rem = sh.tiles32 % slots;
+                // (Measured, one MI355X: C3 0.545 -> 0.517 ms, C4 2.83 -> 2.74 ms on one stream.  When the VAE
+                // kernel runs beside the LSTM on the second stream the CUs are shared between the two grids
+                // and the rounds no longer exist: C4 measured 29.7 M windows/s with one wave per candidate,
+                // 29.5 M with lstm_rec2_kernel for every tile, 28.8 M split — so those calls keep the former.)
+                const int n2 = c->rec2_mode == 0 ? 0 : c->rec2_mode == 2 ? sh.tiles32
+                               : overlap ? 0
+                               : 2 * rem <= slots ? sh.tiles32 - rem : sh.tiles32;
+                if (n2 > 0) {
+                    ra.l.n_tiles = n2; ra.tile0 = 0;
+                    hipLaunchKernelGGL(lstm_rec2_kernel<8>, dim3((n2 + 3) / 4), dim3(256), lds, c->stream, ra);
+                }
+                if (n2 < sh.tiles32) {
+                    ra.l.n_tiles = sh.tiles32; ra.tile0 = n2;
+                    hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3((sh.tiles32 - n2 + 1) / 2), dim3(256), lds, c->stream, ra);
+                }
+            } else if (a.flag_mode > 0) hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
             else hipLaunchKernelGGL((lstm_rec_kernel<8, false>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
             c->last_variant = "xproj+rec";
         } else {
@@ -1080,6 +1106,8 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec2_kernel<8>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 c->rec_attr_set = true;
             }

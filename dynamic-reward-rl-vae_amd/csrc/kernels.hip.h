@@ -17,6 +17,7 @@
 //   lstm_generic_kernel<NT>     fallback LSTM (whole cell per wave, weights from L2)
 //   xproj_kernel<NT>            input projections once per sample
 //   lstm_rec_kernel<NT,FLAGGED> recurrence from the projections, H <= 64
+//   lstm_rec2_kernel<NT>        the same for two candidate states per window, both in one wave
 //   lstm_h128i2_kernel<NG>      univariate H <= 128: U stationary in registers, persistent grid
 //   lstm_h128p_kernel<NG>       the same fed from projections (any input width)
 //   lstm_gemv_kernel<NT>        estimator.predict at batch 1..4 (VALU matrix-vector)
@@ -24,7 +25,7 @@
 // lstm_w16.hip.h adds lstm_h128i2_w16_kernel: the univariate recurrence on 16-window tiles
 // (v_mfma_f32_16x16x4_f32) for calls too small to fill the chip with 32-window tiles.
 // lstm_f16x3.hip.h adds the opt-in 3-term f16-split variant of lstm_h128i2_kernel.
-// VW_ABL / H128_ABL are timing-only ablation switches (wrong results) used to price the parts of a
+// VW_ABL / H128_ABL / REC_ABL are timing-only ablation switches (wrong results) used to price the parts of a
 // kernel; the default build has them off.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -767,6 +768,7 @@ struct RecArgs {
     const float* flagw;      // packed [NT][2][16]: the flag row of Wx in accumulator order
     int win_rows;            // projected rows between consecutive windows: 1 (sliding windows of a series) or
                              // W (explicit estimator.predict states: every state brings its own W rows)
+    int tile0 = 0;           // lstm_rec_kernel / lstm_rec2_kernel: this launch covers tiles [tile0, l.n_tiles)
 };
 
 // 4 waves per workgroup (one per SIMD), each an independent 32-window x 1-candidate recurrence:
@@ -780,6 +782,9 @@ struct RecArgs {
 //    at a time: a 4-slot ring requests tile tl+4 when tile tl is consumed, half a step ahead.
 //  * A fragments come from LDS in groups of 8, one group ahead of their MFMAs, across tile
 //    boundaries too, so the MFMA stream does not drain at a boundary.
+#ifndef REC_ABL
+#define REC_ABL 0     // timing-only ablations (wrong results): 1 no projection refill, 2 no cell update, 3 no flag term, 4 = 1+2
+#endif
 template <int NT>
 __device__ __forceinline__ f32x16 rec_load_p(const char* __restrict__ P, size_t chunk_bytes, unsigned voff, int tl) {
     f32x16 d;
@@ -803,9 +808,11 @@ __device__ __forceinline__ void rec_step(f32x16 (&pq)[4], float (&aq)[2][8], flo
     for (int tl = 0; tl < NT; ++tl) {
         f32x16 acc = pq[tl & 3];
         // refill the slot: tile tl+4 of this step, or tile tl+4-NT of the next one
+#if REC_ABL != 1 && REC_ABL != 4
         pq[tl & 3] = (tl + 4 < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + 4)
                                    : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + 4 - NT);
-        if (FLAGGED) {
+#endif
+        if (FLAGGED && REC_ABL != 3) {
             const f32x16 wf = load_bias16(s_fw, tl, half);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = fmaf(fl, wf[r], acc[r]);
@@ -827,7 +834,11 @@ __device__ __forceinline__ void rec_step(f32x16 (&pq)[4], float (&aq)[2][8], flo
         }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd)
+#if REC_ABL == 2 || REC_ABL == 4
+            hn[tl][qd] = (acc[4 * qd] + acc[4 * qd + 1]) + (acc[4 * qd + 2] + acc[4 * qd + 3]);
+#else
             hn[tl][qd] = lstm_cell(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3], 0.0f, c[tl][qd]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -854,7 +865,9 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
         for (int i = threadIdx.x; i < NT * 32; i += 256) s_fw[i] = ra.flagw[i];
     }
     __syncthreads();
-    const int tile = a.S == 2 ? blockIdx.x * 2 + (wave >> 1) : blockIdx.x * 4 + wave;
+    // two candidate states: waves = {tile, tile+1} x {a0, a1} (the tail of a call, and calls too small
+    // to fill the chip with one wave per tile: see the host side); otherwise 4 tiles
+    const int tile = ra.tile0 + (a.S == 2 ? blockIdx.x * 2 + (wave >> 1) : blockIdx.x * 4 + wave);
     const int cand = a.S == 2 ? (wave & 1) : 0;
     if (tile >= a.n_tiles) return;
     const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
@@ -912,6 +925,125 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
         if (half == 0 && j < count)
             a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = part + a.b_out[act];
     }
+}
+
+// Two candidate states per window (DRL_FLAG_BOTH: the flag column is 0 on every row of candidate 0 and
+// 1 on every row of candidate 1): one wave runs BOTH recurrences of its 32 windows.  They share the
+// projections (loaded once; candidate 1 adds the flag row of Wx) and every A fragment (one LDS read
+// feeds two MFMAs), and the two accumulator chains are independent of each other.  Same sums in the
+// same order as lstm_rec_kernel<NT, true> with flag 0 / 1 (fmaf(1, w, p) == p + w), bit for bit.
+template <int NT, bool FIRST>
+__device__ __forceinline__ void rec_step2(f32x16 (&pq)[4], float (&aq)[2][8], float (&c)[2][NT][4], float (&h)[2][NT][4],
+                                          const float* __restrict__ ul, const float* __restrict__ s_fw,
+                                          const char* __restrict__ Pb, size_t chunk_bytes, unsigned voff_t,
+                                          unsigned voff_n, int half) {
+    float hn[2][NT][4];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        f32x16 acc0 = pq[tl & 3], acc1;
+        pq[tl & 3] = (tl + 4 < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + 4)
+                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + 4 - NT);
+        {
+            const f32x16 wf = load_bias16(s_fw, tl, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = acc0[r] + wf[r];
+        }
+        if (!FIRST) {
+#pragma unroll
+            for (int g = 0; g < NT / 2; ++g) {
+                const int ng = (g + 1) % (NT / 2), ntl = (g + 1 < NT / 2) ? tl : (tl + 1) % NT;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) aq[(g + 1) & 1][i] = ul[((ng * 8 + i) * NT + ntl) * 64];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = g * 8 + i;
+                    acc0 = mfma32(aq[g & 1][i], h[0][kk >> 2][kk & 3], acc0);
+                    acc1 = mfma32(aq[g & 1][i], h[1][kk >> 2][kk & 3], acc1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            hn[0][tl][qd] = lstm_cell(acc0[4 * qd], acc0[4 * qd + 1], acc0[4 * qd + 2], acc0[4 * qd + 3], 0.0f, c[0][tl][qd]);
+            hn[1][tl][qd] = lstm_cell(acc1[4 * qd], acc1[4 * qd + 1], acc1[4 * qd + 2], acc1[4 * qd + 3], 0.0f, c[1][tl][qd]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int cd = 0; cd < 2; ++cd)
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) h[cd][tl][qd] = hn[cd][tl][qd];
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void lstm_rec2_kernel(RecArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64] | flag row [NT][2][16]
+    static_assert(NT % 4 == 0, "the projection ring assumes a multiple of 4 gate tiles");
+    const LstmArgs& a = ra.l;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, j = lane & 31;
+    float* s_fw = rec_u + NT * 4 * NT * 64;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.u);
+        f32x4* dst = reinterpret_cast<f32x4*>(rec_u);
+        for (int i = threadIdx.x; i < NT * 4 * NT * 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < NT * 32; i += 256) s_fw[i] = ra.flagw[i];
+    }
+    __syncthreads();
+    const int tile = ra.tile0 + blockIdx.x * 4 + wave;
+    if (tile >= a.n_tiles) return;
+    const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
+    const long long samp0 = a.seg.samp_off[s];
+    const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
+    const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 32;
+    const int count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
+    const int jj = j < count ? j : count - 1;
+    const long long nrow0 = samp0 + a.row0 + (k0 + jj) * ra.win_rows;
+    const float* __restrict__ ul = rec_u + lane;
+    const char* __restrict__ Pb = reinterpret_cast<const char*>(ra.P);
+    const size_t chunk_bytes = (size_t)ra.n_samples * 32;
+    const unsigned voff0 = (unsigned)((size_t)nrow0 * 32 + half * 16);
+    const int W = a.W;
+
+    f32x16 pq[4];
+    float c[2][NT][4], h[2][NT][4];
+#pragma unroll
+    for (int cd = 0; cd < 2; ++cd)
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { c[cd][tl][qd] = 0.0f; h[cd][tl][qd] = 0.0f; }
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) pq[tl] = rec_load_p<NT>(Pb, chunk_bytes, voff0, tl);
+    float aq[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aq[0][i] = ul[(i * NT + 0) * 64];
+
+    rec_step2<NT, true>(pq, aq, c, h, ul, s_fw, Pb, chunk_bytes, voff0, voff0 + (unsigned)(1 < W ? 1 : 0) * 32u, half);
+    for (int t = 1; t < W; ++t) {
+        const int tn = t + 1 < W ? t + 1 : t;
+        rec_step2<NT, false>(pq, aq, c, h, ul, s_fw, Pb, chunk_bytes, voff0 + (unsigned)t * 32u,
+                             voff0 + (unsigned)tn * 32u, half);
+    }
+
+#pragma unroll
+    for (int cd = 0; cd < 2; ++cd)
+        for (int act = 0; act < a.A; ++act) {
+            float part = 0.0f;
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int unit = 8 * tl + 2 * qd + half;
+                    part = fmaf(h[cd][tl][qd], unit < a.H ? a.w_out[unit * a.A + act] : 0.0f, part);
+                }
+            part += __shfl_xor(part, 32);
+            if (half == 0 && j < count)
+                a.q[((a.seg.win_off[s] + k0 + j) * 2 + cd) * a.A + act] = part + a.b_out[act];
+        }
 }
 
 // Univariate fast path (I = 2, H = 128): one workgroup of 4 waves = 64 consecutive windows in two

@@ -2,6 +2,8 @@
 feature counts, hidden widths, VAE depths, ragged batches with too-short series, every flag mode,
 device-side MinMax, RobustScaler/clip — the corners the named configurations do not visit.
 Same tolerance as tests/test_gpu_parity.py (1e-5 relative, fp32)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -142,6 +144,69 @@ def test_multivariate_random_shapes(scorer, seed):
         assert np.array_equal(out["action"][pos:pos + k][safe], want["action"][safe])
         pos += k
     assert pos == K
+
+
+_rec2 = []
+
+
+def _rec2_scorer():
+    """A context created with DRLVAE_REC2=2: two-candidate calls of any size take lstm_rec2_kernel (by
+    default only whole rounds of 4*CUs tiles do, i.e. calls of 16k windows and more)."""
+    if not _rec2:
+        from drlvae.scorer import WindowScorer
+        os.environ["DRLVAE_REC2"] = "2"
+        try:
+            _rec2.append(WindowScorer(0))
+        finally:
+            del os.environ["DRLVAE_REC2"]
+    return _rec2[0]
+
+
+@pytest.mark.parametrize("F,H,Wn", [(5, 64, 25), (38, 40, 7), (3, 16, 1), (17, 128, 12)])
+def test_two_candidates_match_constant_explicit_flags_bit_for_bit(scorer, F, H, Wn):
+    """DRL_FLAG_BOTH can run both candidate states of a window in one wave (lstm_rec2_kernel: shared
+    projections, shared weight fragments) or one wave per candidate; explicit per-sample flags of all
+    0 / all 1 run the single-candidate kernel.  All three must agree bit for bit."""
+    rng = np.random.default_rng(77 + F)
+    lstm = synth_lstm(rng, F + 1, H)
+    scorer.set_lstm(lstm)
+    lens = [Wn + 70, Wn, Wn + 1, Wn + 33]
+    x = rng.random((sum(lens), F), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    both = scorer.score(x, Wn, off, vae_lag=0, flag_mode="both", want=("q",))["q"]
+    assert both.shape == (104, 2, 2)
+    r2 = _rec2_scorer()
+    r2.set_lstm(lstm)
+    both2 = r2.score(x, Wn, off, vae_lag=0, flag_mode="both", want=("q",))["q"]
+    assert np.array_equal(both2.view(np.uint32), both.view(np.uint32)), (F, H)
+    for cand in (0, 1):
+        fl = np.full(len(x), float(cand), np.float32)
+        one = scorer.score(x, Wn, off, vae_lag=0, flag_mode="explicit", flags=fl, want=("q",))["q"]
+        assert np.array_equal(one.view(np.uint32), both[:, cand].view(np.uint32)), (F, H, cand)
+
+
+def test_two_candidate_call_split_between_the_kernels():
+    """A call of a little more than one round of tiles (4*CUs tiles of 32 windows): whole rounds run
+    lstm_rec2_kernel, the remainder one wave per candidate.  Periodic input, so every period must
+    score identically whichever kernel its tile lands on."""
+    from drlvae.scorer import WindowScorer
+    rng = np.random.default_rng(5)
+    F, H, Wn, P = 6, 64, 10, 96                       # P: a multiple of the 32-window tile
+    lstm = synth_lstm(rng, F + 1, H)
+    sc = WindowScorer(0)
+    try:
+        sc.set_lstm(lstm)
+        import torch
+        n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+        n_win = (4 * n_cu + 100) * 32                   # one whole round + 100 tiles
+        period = rng.random((P, F), dtype=np.float32)
+        x = np.concatenate([period] * ((n_win + Wn) // P + 1))[:n_win + Wn]
+        q = sc.score(x, Wn, vae_lag=0, flag_mode="both", want=("q",))["q"]
+        assert q.shape == (n_win, 2, 2)
+        full = q[:(n_win // P) * P].reshape(-1, P, 2, 2)
+        assert np.array_equal(full.view(np.uint32), np.broadcast_to(full[:1], full.shape).view(np.uint32))
+    finally:
+        sc.close()
 
 
 @pytest.mark.parametrize("Wn,F,H", [(1, 1, 128), (1, 3, 64), (2, 1, 8), (1, 5, 104), (191, 1, 128), (200, 1, 128)])
