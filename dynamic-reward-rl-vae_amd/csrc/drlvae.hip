@@ -95,6 +95,11 @@ struct drl_ctx {
     DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
     void* pinned = nullptr;     // pinned host staging for the segment tables
     size_t pinned_cap = 0;
+    // pinned, device-mapped host memory for the inputs and outputs of the per-step calls (vae.predict /
+    // estimator.predict on one state): the kernel reads and writes it directly, so such a call is one
+    // launch and one stream synchronisation, no copies
+    void* pin_io = nullptr;
+    size_t pin_io_cap = 0;
     Prof prof;
     const char* last_variant = "none";
     int last_tile = 0;   // windows per workgroup tile of the last LSTM launch (0: not a tiled kernel)
@@ -143,6 +148,16 @@ int ensure_pinned(drl_ctx* c, size_t bytes) {
     c->pinned_cap = cap;
     return DRL_OK;
 }
+
+int ensure_pin_io(drl_ctx* c, size_t bytes) {
+    if (bytes <= c->pin_io_cap) return DRL_OK;
+    if (c->pin_io) { HIP_TRY(c, hipHostFree(c->pin_io)); c->pin_io = nullptr; c->pin_io_cap = 0; }
+    size_t cap = std::max<size_t>(bytes, 64 * 1024);
+    HIP_TRY(c, hipHostMalloc(&c->pin_io, cap, hipHostMallocDefault));
+    c->pin_io_cap = cap;
+    return DRL_OK;
+}
+constexpr size_t PIN_IO_MAX = 256 * 1024;   // larger calls are staged with copies (PCIe bandwidth, not latency, matters there)
 
 inline int rowmap_h(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 inline size_t up16(size_t n) { return (n + 15) & ~size_t(15); }
@@ -368,6 +383,7 @@ void drl_destroy(drl_ctx* c) {
                       &c->st_err, &c->st_q, &c->st_act, &c->st_margin})
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pin_io) (void)hipHostFree(c->pin_io);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -990,17 +1006,36 @@ int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, flo
     HIP_TRY(c, hipSetDevice(c->device));
     const int D = c->vae.D;
     int rc;
-    const size_t nb = (size_t)B * D * sizeof(float);
-    if ((rc = ensure(c, c->st_in, nb))) return rc;
-    if ((rc = ensure(c, c->st_q, nb))) return rc;           // reconstruction staging
-    if ((rc = ensure(c, c->st_err, (size_t)B * sizeof(float)))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, x, nb, hipMemcpyHostToDevice, c->stream));
-    const float* d_eps = nullptr;
-    if (eps) {
-        const size_t n = (size_t)B * c->vae.latent * sizeof(float);
-        if ((rc = ensure(c, c->st_eps, n))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->st_eps.p, eps, n, hipMemcpyHostToDevice, c->stream));
-        d_eps = (const float*)c->st_eps.p;
+    const size_t nb = (size_t)B * D * sizeof(float), eb = (size_t)B * sizeof(float);
+    const size_t nz = eps ? (size_t)B * c->vae.latent * sizeof(float) : 0;
+    // the reference's per-step call (one window): inputs and outputs in mapped host memory, no copies
+    const bool direct = B <= 32 && 2 * up16(nb) + up16(eb) + up16(nz) <= PIN_IO_MAX;
+    const float *d_x, *d_eps = nullptr;
+    float *d_rec, *d_err;
+    if (direct) {
+        if ((rc = ensure_pin_io(c, 2 * up16(nb) + up16(eb) + up16(nz)))) return rc;
+        char* base = (char*)c->pin_io;
+        memcpy(base, x, nb);
+        d_x = (const float*)base;
+        d_rec = (float*)(base + up16(nb));
+        d_err = (float*)(base + 2 * up16(nb));
+        if (eps) {
+            memcpy(base + 2 * up16(nb) + up16(eb), eps, nz);
+            d_eps = (const float*)(base + 2 * up16(nb) + up16(eb));
+        }
+    } else {
+        if ((rc = ensure(c, c->st_in, nb))) return rc;
+        if ((rc = ensure(c, c->st_q, nb))) return rc;           // reconstruction staging
+        if ((rc = ensure(c, c->st_err, eb))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->st_in.p, x, nb, hipMemcpyHostToDevice, c->stream));
+        if (eps) {
+            if ((rc = ensure(c, c->st_eps, nz))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->st_eps.p, eps, nz, hipMemcpyHostToDevice, c->stream));
+            d_eps = (const float*)c->st_eps.p;
+        }
+        d_x = (const float*)c->st_in.p;
+        d_rec = (float*)c->st_q.p;
+        d_err = (float*)c->st_err.p;
     }
     const int64_t off[2] = {0, B};
     SegHost sh;
@@ -1008,20 +1043,26 @@ int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, flo
     VaeArgs a;
     memset(&a, 0, sizeof a);
     fill_vae_args(c, a);
-    a.x = (const float*)c->st_in.p; a.win_stride = D; a.lag_elems = 0; a.D = D;
+    a.x = d_x; a.win_stride = D; a.lag_elems = 0; a.D = D;
     a.eps = d_eps;
     a.seg.samp_off = sh.d_samp; a.seg.win_off = sh.d_win; a.seg.tile_off = sh.d_t32; a.seg.n_seg = 1; a.seg.W = 0;
     a.n_tiles = sh.tiles32;
-    a.err = (float*)c->st_err.p;
-    a.recon = recon ? (float*)c->st_q.p : nullptr;
+    a.err = d_err;
+    a.recon = recon ? d_rec : nullptr;
     prof_begin(c, 1, c->stream);
     if (c->vae.narrow) hipLaunchKernelGGL(vae_kernel<2>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(vae_kernel<DRL_VAE_MAX_TILES>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
     prof_end(c, c->stream);
     HIP_TRY(c, hipGetLastError());
-    if (recon) HIP_TRY(c, hipMemcpyAsync(recon, c->st_q.p, nb, hipMemcpyDeviceToHost, c->stream));
-    if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (!direct) {
+        if (recon) HIP_TRY(c, hipMemcpyAsync(recon, c->st_q.p, nb, hipMemcpyDeviceToHost, c->stream));
+        if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, eb, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (direct) {
+        if (recon) memcpy(recon, d_rec, nb);
+        if (recon_err) memcpy(recon_err, d_err, eb);
+    }
     return DRL_OK;
 }
 
@@ -1033,27 +1074,42 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     HIP_TRY(c, hipSetDevice(c->device));
     const int I = c->lstm.I, A = c->lstm.A;
     int rc;
-    const size_t nb = (size_t)B * W * I * sizeof(float);
-    if ((rc = ensure(c, c->st_in, nb))) return rc;
-    if ((rc = ensure(c, c->st_q, (size_t)B * A * sizeof(float)))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, states, nb, hipMemcpyHostToDevice, c->stream));
+    const size_t nb = (size_t)B * W * I * sizeof(float), qb = (size_t)B * A * sizeof(float);
+    const int gv_rows = 32 * c->lstm.NT, gv_ip = (I + 3) & ~3;
+    const size_t gv_lds = ((size_t)W * gv_ip + (size_t)W * gv_rows) * sizeof(float);
+    const bool gemv = B <= 4 && W <= GEMV_WMAX && gv_lds <= 150 * 1024;
+    // the matrix-vector kernel stages its state into LDS in one pass and writes A floats: it can work
+    // on mapped host memory directly
+    const bool direct = gemv && up16(nb) + qb <= PIN_IO_MAX;
+    const float* d_in;
+    float* d_q;
+    if (direct) {
+        if ((rc = ensure_pin_io(c, up16(nb) + qb))) return rc;
+        memcpy(c->pin_io, states, nb);
+        d_in = (const float*)c->pin_io;
+        d_q = (float*)((char*)c->pin_io + up16(nb));
+    } else {
+        if ((rc = ensure(c, c->st_in, nb))) return rc;
+        if ((rc = ensure(c, c->st_q, qb))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->st_in.p, states, nb, hipMemcpyHostToDevice, c->stream));
+        d_in = (const float*)c->st_in.p;
+        d_q = (float*)c->st_q.p;
+    }
     const int64_t off[2] = {0, B};
     SegHost sh;
     if ((rc = build_segments(c, off, 1, 0, true, sh))) return rc;
     LstmArgs a;
     memset(&a, 0, sizeof a);
     fill_lstm_args(c, a);
-    a.W = W; a.x = (const float*)c->st_in.p; a.F = I; a.win_stride = (long long)W * I; a.row_stride = I; a.row0 = 0;
+    a.W = W; a.x = d_in; a.F = I; a.win_stride = (long long)W * I; a.row_stride = I; a.row0 = 0;
     a.flag_mode = -1; a.flags = nullptr;
     a.seg.samp_off = sh.d_samp; a.seg.win_off = sh.d_win; a.seg.tile_off = sh.d_t32; a.seg.n_seg = 1; a.seg.W = W;
-    a.n_tiles = sh.tiles32; a.S = 1; a.q = (float*)c->st_q.p;
+    a.n_tiles = sh.tiles32; a.S = 1; a.q = d_q;
     // the segment table counts "samples" = windows here; the kernel multiplies samp_off (0) only
     const dim3 grid((sh.tiles32 + 3) / 4, 1);
     c->last_tile = 0;
     prof_begin(c, 0, c->stream);
-    const int gv_rows = 32 * c->lstm.NT, gv_ip = (I + 3) & ~3;
-    const size_t gv_lds = ((size_t)W * gv_ip + (size_t)W * gv_rows) * sizeof(float);
-    if (B <= 4 && W <= GEMV_WMAX && gv_lds <= 150 * 1024) {
+    if (gemv) {
         // the per-step call of the reference's RL loop: a matrix-vector kernel, one workgroup per state
         if (gv_lds > c->gemv_lds_set) {
             HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_gemv_kernel<8>),
@@ -1131,8 +1187,9 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     }
     prof_end(c, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (!direct) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, qb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (direct) memcpy(q, d_q, qb);
     return DRL_OK;
 }
 
