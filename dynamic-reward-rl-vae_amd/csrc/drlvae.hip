@@ -38,6 +38,7 @@ struct VaeHost {
     int latent = 0;
     int D = 0;                            // input width
     bool narrow = false;                  // every hidden width <= 64: vae_kernel<2>
+    size_t pack_floats = 0;               // size of the whole weight pack
 };
 
 struct LstmHost {
@@ -105,6 +106,7 @@ struct drl_ctx {
     int last_tile = 0;   // windows per workgroup tile of the last LSTM launch (0: not a tiled kernel)
     const char* last_vae_variant = "none";
     size_t wide_lds_set = 0, gemv_lds_set = 0;
+    bool chain_lds_set = false;
     // the segment tables of the last call stay valid on the device while the same series layout is scored again
     std::vector<int64_t> seg_key;
     long long seg_K = 0;
@@ -310,6 +312,36 @@ void fill_vae_args(drl_ctx* c, VaeArgs& a) {
     a.w_lv = v.has_lv ? base + v.wlv_off : nullptr;
     a.b_lv = v.has_lv ? base + v.blv_off : nullptr;
     a.lv_clip = v.lv_clip;
+    a.pack = base;
+    a.pack_floats = (int)v.pack_floats;
+}
+
+// The chain kernel: with its weights copied to LDS first when the call is at most one workgroup per
+// CU (nothing else would hide the weight-load latency) and the pack fits.
+#ifndef DRL_CHAIN_LDS_MAX
+#define DRL_CHAIN_LDS_MAX (128 * 1024)     // 0 (build flag): never, for A/B timing
+#endif
+constexpr size_t CHAIN_LDS_MAX = DRL_CHAIN_LDS_MAX;
+int launch_vae_chain(drl_ctx* c, const VaeArgs& a, int tiles32, hipStream_t st) {
+    const dim3 grid((tiles32 + 3) / 4);
+    const size_t pack_bytes = c->vae.pack_floats * sizeof(float);
+    if ((int)grid.x <= c->n_cu && pack_bytes <= CHAIN_LDS_MAX) {
+        if (!c->chain_lds_set) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_kernel<2, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_kernel<DRL_VAE_MAX_TILES, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_MAX));
+            c->chain_lds_set = true;
+        }
+        if (c->vae.narrow) hipLaunchKernelGGL((vae_kernel<2, true>), grid, dim3(256), pack_bytes, st, a);
+        else hipLaunchKernelGGL((vae_kernel<DRL_VAE_MAX_TILES, true>), grid, dim3(256), pack_bytes, st, a);
+        c->last_vae_variant = "chain/lds";
+    } else {
+        if (c->vae.narrow) hipLaunchKernelGGL((vae_kernel<2, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((vae_kernel<DRL_VAE_MAX_TILES, false>), grid, dim3(256), 0, st, a);
+        c->last_vae_variant = "chain";
+    }
+    return DRL_OK;
 }
 
 void fill_lstm_args(drl_ctx* c, LstmArgs& a) {
@@ -472,6 +504,7 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
         v.blv_off = off; off += up16(nout * 32);
     }
     v.lv_clip = std::isfinite(logvar_clip) ? logvar_clip : 0.0f;
+    v.pack_floats = off;
     std::vector<float> pack(off, 0.0f);
     for (int p = 0; p < v.n_path; ++p) {
         const int l = path[p];
@@ -754,9 +787,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, vst, a, xr_floats);
             c->last_vae_variant = "wide";
         } else {
-            if (c->vae.narrow) hipLaunchKernelGGL(vae_kernel<2>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, vst, a);
-            else hipLaunchKernelGGL(vae_kernel<DRL_VAE_MAX_TILES>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, vst, a);
-            c->last_vae_variant = "chain";
+            int rcl = launch_vae_chain(c, a, sh.tiles32, vst);
+            if (rcl) return rcl;
         }
         prof_end(c, vst);
         HIP_TRY(c, hipGetLastError());
@@ -1050,8 +1082,7 @@ int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, flo
     a.err = d_err;
     a.recon = recon ? d_rec : nullptr;
     prof_begin(c, 1, c->stream);
-    if (c->vae.narrow) hipLaunchKernelGGL(vae_kernel<2>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(vae_kernel<DRL_VAE_MAX_TILES>, dim3((sh.tiles32 + 3) / 4), dim3(256), 0, c->stream, a);
+    if ((rc = launch_vae_chain(c, a, sh.tiles32, c->stream))) return rc;
     prof_end(c, c->stream);
     HIP_TRY(c, hipGetLastError());
     if (!direct) {

@@ -151,6 +151,9 @@ struct VaeArgs {
     // outputs
     float* err;                              // [K_total] or null
     float* recon;                            // [K_total, D] or null (drl_vae_predict)
+    // the whole weight pack (every w/b pointer above points into it): vae_kernel<.., true> copies it to LDS
+    const float* pack;
+    int pack_floats;                         // a multiple of 16
 };
 
 // act 3 = sigmoid whose layer was packed pre-scaled by -log2(e): 1/(1+2^y)
@@ -186,23 +189,62 @@ __device__ __forceinline__ f32x16 load_bias16(const float* __restrict__ bp, int 
     return v;
 }
 
-__device__ __forceinline__ float vae_input(const VaeArgs& a, const float* __restrict__ xin, int d,
-                                           bool has_norm, float sc, float of) {
-    if (d >= a.D) return 0.0f;
-    float v = xin[d];
-    if (has_norm) v = minmax_apply(v, sc, of);
-    if (a.center) {
-        v = (v - a.center[d]) / a.scale[d];
-        if (a.clip > 0.0f) v = fminf(fmaxf(v, -a.clip), a.clip);
+// The 16 inputs one lane feeds to the MFMAs of input tile `it` (features it*32 + rowmap(r, half)).
+// All loads are issued before the first use (clamped indices instead of a branch per element: one
+// round trip to memory per tile, not sixteen).
+__device__ __forceinline__ void vae_input16(const VaeArgs& a, const float* __restrict__ xin, int it, int half,
+                                            bool has_norm, float sc, float of, float (&bv)[16]) {
+    int dc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = it * 32 + rowmap(r, half);
+        dc[r] = d < a.D ? d : a.D - 1;
+        bv[r] = xin[dc[r]];
     }
-    return v;
+    if (has_norm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = minmax_apply(bv[r], sc, of);
+    }
+    if (a.center) {
+        float ce[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ce[r] = a.center[dc[r]]; sv[r] = a.scale[dc[r]]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bv[r] = (bv[r] - ce[r]) / sv[r];
+            if (a.clip > 0.0f) bv[r] = fminf(fmaxf(bv[r], -a.clip), a.clip);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = (it * 32 + rowmap(r, half)) < a.D ? bv[r] : 0.0f;
 }
 
 // MAXT = accumulator tiles kept per layer: 2 when every hidden width is <= 64 (the univariate
 // VAEs), else MAXT.  The kernel is latency-bound (weights come from L2 per MFMA, 256
 // MFMAs per 32 windows), so the narrow instantiation's lower register count buys resident waves.
-template <int MAXT>
-__global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a) {
+// LDSW: calls of a few tiles (vae.predict on one window, one short series) have nothing to hide that
+// latency with — one wave waits ~1-2 us per group of weight loads, 40 us for the chain.  There the
+// workgroup first copies the whole weight pack (70 KB for the univariate VAEs) to LDS, all loads in
+// flight at once, and the chain reads its A fragments from LDS.  Same MFMAs in the same order.
+template <int MAXT, bool LDSW = false>
+__global__ __launch_bounds__(256, (LDSW ? 1 : (MAXT <= 2 ? 3 : 1))) void vae_kernel(VaeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float vk_pack[];
+    if constexpr (LDSW) {
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.pack);
+        f32x4* dst = reinterpret_cast<f32x4*>(vk_pack);
+        const int n4 = a.pack_floats >> 2;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * 256 < n4) t[u] = src[i0 + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * 256 < n4) dst[i0 + u * 256] = t[u];
+        }
+        __syncthreads();
+    }
+    auto wp = [&](const float* g) -> const float* {
+        if constexpr (LDSW) return vk_pack + (g - a.pack); else return g;
+    };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
     const int tile = blockIdx.x * 4 + wave;
@@ -226,18 +268,19 @@ __global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a
     // ---- layer 0: input from memory
     {
         const int nin = (a.din[0] + 31) >> 5, nout = (a.dout[0] + 31) >> 5;
-        const float* __restrict__ w = a.w[0];
+        const float* __restrict__ w = wp(a.w[0]);
 #pragma unroll
         for (int ot = 0; ot < MAXT; ++ot)
-            cur[ot] = ot < nout ? load_bias16(a.b[0], ot, half) : f32x16{};
+            cur[ot] = ot < nout ? load_bias16(wp(a.b[0]), ot, half) : f32x16{};
         for (int it = 0; it < nin; ++it) {
+            float bv[16];
+            vae_input16(a, xin, it, half, has_norm, sc, of, bv);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float bv = vae_input(a, xin, it * 32 + rowmap(r, half), has_norm, sc, of);
 #pragma unroll
                 for (int ot = 0; ot < MAXT; ++ot)
                     if (ot < nout)
-                        cur[ot] = mfma32(w[(((size_t)it * nout + ot) * 16 + r) * 64 + lane], bv, cur[ot]);
+                        cur[ot] = mfma32(w[(((size_t)it * nout + ot) * 16 + r) * 64 + lane], bv[r], cur[ot]);
             }
         }
 #pragma unroll
@@ -247,13 +290,14 @@ __global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a
     // ---- middle layers: registers -> registers
     for (int p = 1; p < a.n - 1; ++p) {
         const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
-        const float* __restrict__ w = a.w[p];
+        const float* __restrict__ w = wp(a.w[p]);
+        const float* __restrict__ wlv = wp(a.w_lv);
         const bool with_lv = (p == a.mu_idx) && a.eps != nullptr;
         f32x16 lv = {};
 #pragma unroll
         for (int ot = 0; ot < MAXT; ++ot)
-            nxt[ot] = ot < nout ? load_bias16(a.b[p], ot, half) : f32x16{};
-        if (with_lv) lv = load_bias16(a.b_lv, 0, half);
+            nxt[ot] = ot < nout ? load_bias16(wp(a.b[p]), ot, half) : f32x16{};
+        if (with_lv) lv = load_bias16(wp(a.b_lv), 0, half);
 #pragma unroll
         for (int it = 0; it < MAXT; ++it) {
             if (it < nin) {
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a
                         if (ot < nout)
                             nxt[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], nxt[ot]);
                     if (with_lv)   // latent <= 32: one output tile
-                        lv = mfma32(a.w_lv[(((size_t)it) * 16 + r) * 64 + lane], cur[it][r], lv);
+                        lv = mfma32(wlv[(((size_t)it) * 16 + r) * 64 + lane], cur[it][r], lv);
                 }
             }
         }
@@ -288,10 +332,12 @@ __global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a
     {
         const int p = a.n - 1;
         const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
-        const float* __restrict__ w = a.w[p];
+        const float* __restrict__ w = wp(a.w[p]);
         float sq = 0.0f;
         for (int ot = 0; ot < nout; ++ot) {
-            f32x16 acc = load_bias16(a.b[p], ot, half);
+            f32x16 acc = load_bias16(wp(a.b[p]), ot, half);
+            float xv16[16];                              // requested before the MFMAs that hide them
+            vae_input16(a, xin, ot, half, has_norm, sc, of, xv16);
 #pragma unroll
             for (int it = 0; it < MAXT; ++it) {
                 if (it < nin) {
@@ -305,7 +351,7 @@ __global__ __launch_bounds__(256, (MAXT <= 2 ? 3 : 1)) void vae_kernel(VaeArgs a
             for (int r = 0; r < 16; ++r) {
                 const int d = ot * 32 + rowmap(r, half);
                 const float y = acc[r];
-                const float xv = vae_input(a, xin, d, has_norm, sc, of);
+                const float xv = xv16[r];
                 if (d < a.D) {
                     const float df = y - xv;
                     sq = fmaf(df, df, sq);

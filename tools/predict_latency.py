@@ -23,3 +23,14 @@ for _ in range(20): sc.vae_predict(x)
 t0 = time.perf_counter()
 for _ in range(200): sc.vae_predict(x)
 print(f"vae.predict batch 1: {(time.perf_counter() - t0) / 200 * 1e6:8.1f} us per call")
+# where the time of a batch-1 call goes: the kernel itself (HIP events around the launch)
+s = rng.random((1, 25, 2), dtype=np.float32)
+sc.profile(True); sc.profile_reset()
+for _ in range(200): sc.q_predict(s)
+ms, n = sc.profile_read(0)
+print(f"  of which the matrix-vector kernel: {ms / max(n, 1) * 1e3:.1f} us (HIP events)")
+sc.profile_reset()
+for _ in range(200): sc.vae_predict(x)
+ms, n = sc.profile_read(1)
+print(f"  vae kernel: {ms / max(n, 1) * 1e3:.1f} us")
+sc.profile(False)
