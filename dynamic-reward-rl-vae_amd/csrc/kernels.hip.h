@@ -1475,6 +1475,11 @@ __global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
 // Every sum runs in the order the MFMA kernels use (bias, input features 0..I-1, units 0..H-1), so
 // the result is bit-identical to theirs.  W <= GEMV_WMAX.
 #define GEMV_WMAX 64
+// lane l of a quad gets lane K of its quad (DPP quad_perm: a plain VALU move, no LDS round trip)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
 template <int NT>
 __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
     constexpr int ROWS = 32 * NT, HP = 8 * NT;
@@ -1541,9 +1546,7 @@ __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
             for (int u = 0; u < HP; ++u) z = fmaf(U[u], hs[u], z);
         }
         // the four gates of a unit sit in four consecutive lanes
-        const int q0 = (threadIdx.x & 63) & ~3;
-        const float zi = __shfl(z, q0 + 0), zj = __shfl(z, q0 + 1), zf = __shfl(z, q0 + 2), zo = __shfl(z, q0 + 3);
-        const float hv = lstm_cell(zi, zj, zf, zo, a.forget_bias, c);
+        const float hv = lstm_cell(quad_bcast<0>(z), quad_bcast<1>(z), quad_bcast<2>(z), quad_bcast<3>(z), a.forget_bias, c);
         if ((i & 3) == 0) s_h[(t + 1) & 1][8 * tau + (i >> 2)] = hv;
         __syncthreads();
     }
