@@ -5,8 +5,10 @@ set -e
 out=gpurun_out/round; mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 300 python -u bench.py > $out/bench_c2.json 2> $out/bench_c2.err
-for w in c1 c3 c4 c5; do
-  timeout -k 10 300 python -u bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_$w.json 2> $out/bench_$w.err
+# short steps need more of them for a stable figure (C1: 0.14 ms per step, C3: 0.75 ms)
+for spec in "c1 300 20" "c3 40 5" "c4 8 2" "c5 5 2"; do
+  set -- $spec
+  timeout -k 10 300 python -u bench.py --workload $1 --steps $2 --warmup $3 --no-cpu-baseline > $out/bench_$1.json 2> $out/bench_$1.err
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --no-cpu-baseline > $out/trace_c2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c4 -- python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c4.log 2>&1
