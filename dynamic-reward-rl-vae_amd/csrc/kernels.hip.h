@@ -828,6 +828,10 @@ struct RecArgs {
 //    at a time: a 4-slot ring requests tile tl+4 when tile tl is consumed, half a step ahead.
 //  * A fragments come from LDS in groups of 8, one group ahead of their MFMAs, across tile
 //    boundaries too, so the MFMA stream does not drain at a boundary.
+#ifndef REC_RING
+#define REC_RING 4      // projection tiles in flight per wave (<= NT); 2, 4 and 8 measure the same (C3, C4):
+                        // the refill is bound by L2/fabric throughput, not by latency
+#endif
 #ifndef REC_ABL
 #define REC_ABL 0     // timing-only ablations (wrong results): 1 no projection refill, 2 no cell update, 3 no flag term, 4 = 1+2
 #endif
@@ -845,18 +849,18 @@ __device__ __forceinline__ f32x16 rec_load_p(const char* __restrict__ P, size_t 
 
 // One step of one wave.  FIRST: h = 0, so only the projections (and the flag term) enter the cell.
 template <int NT, bool FLAGGED, bool FIRST>
-__device__ __forceinline__ void rec_step(f32x16 (&pq)[4], float (&aq)[2][8], float (&c)[NT][4], float (&h)[NT][4],
+__device__ __forceinline__ void rec_step(f32x16 (&pq)[REC_RING], float (&aq)[2][8], float (&c)[NT][4], float (&h)[NT][4],
                                          const float* __restrict__ ul, const float* __restrict__ s_fw,
                                          const char* __restrict__ Pb, size_t chunk_bytes, unsigned voff_t,
                                          unsigned voff_n, float fl, int half) {
     float hn[NT][4];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-        f32x16 acc = pq[tl & 3];
+        f32x16 acc = pq[tl % REC_RING];
         // refill the slot: tile tl+4 of this step, or tile tl+4-NT of the next one
 #if REC_ABL != 1 && REC_ABL != 4
-        pq[tl & 3] = (tl + 4 < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + 4)
-                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + 4 - NT);
+        pq[tl % REC_RING] = (tl + REC_RING < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + REC_RING)
+                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + REC_RING - NT);
 #endif
         if (FLAGGED && REC_ABL != 3) {
             const f32x16 wf = load_bias16(s_fw, tl, half);
@@ -932,14 +936,14 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
     const unsigned voff0 = (unsigned)((size_t)nrow0 * 32 + half * 16);
     const int W = a.W;
 
-    f32x16 pq[4];
+    f32x16 pq[REC_RING];
     float c[NT][4], h[NT][4];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) { c[tl][qd] = 0.0f; h[tl][qd] = 0.0f; }
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl) pq[tl] = rec_load_p<NT>(Pb, chunk_bytes, voff0, tl);
+    for (int tl = 0; tl < REC_RING; ++tl) pq[tl] = rec_load_p<NT>(Pb, chunk_bytes, voff0, tl);
     float aq[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) aq[0][i] = ul[(i * NT + 0) * 64];
@@ -979,16 +983,16 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
 // feeds two MFMAs), and the two accumulator chains are independent of each other.  Same sums in the
 // same order as lstm_rec_kernel<NT, true> with flag 0 / 1 (fmaf(1, w, p) == p + w), bit for bit.
 template <int NT, bool FIRST>
-__device__ __forceinline__ void rec_step2(f32x16 (&pq)[4], float (&aq)[2][8], float (&c)[2][NT][4], float (&h)[2][NT][4],
+__device__ __forceinline__ void rec_step2(f32x16 (&pq)[REC_RING], float (&aq)[2][8], float (&c)[2][NT][4], float (&h)[2][NT][4],
                                           const float* __restrict__ ul, const float* __restrict__ s_fw,
                                           const char* __restrict__ Pb, size_t chunk_bytes, unsigned voff_t,
                                           unsigned voff_n, int half) {
     float hn[2][NT][4];
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
-        f32x16 acc0 = pq[tl & 3], acc1;
-        pq[tl & 3] = (tl + 4 < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + 4)
-                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + 4 - NT);
+        f32x16 acc0 = pq[tl % REC_RING], acc1;
+        pq[tl % REC_RING] = (tl + REC_RING < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + REC_RING)
+                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + REC_RING - NT);
         {
             const f32x16 wf = load_bias16(s_fw, tl, half);
 #pragma unroll
@@ -1054,7 +1058,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec2_kernel(RecArgs ra) {
     const unsigned voff0 = (unsigned)((size_t)nrow0 * 32 + half * 16);
     const int W = a.W;
 
-    f32x16 pq[4];
+    f32x16 pq[REC_RING];
     float c[2][NT][4], h[2][NT][4];
 #pragma unroll
     for (int cd = 0; cd < 2; ++cd)
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(256, 1) void lstm_rec2_kernel(RecArgs ra) {
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) { c[cd][tl][qd] = 0.0f; h[cd][tl][qd] = 0.0f; }
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl) pq[tl] = rec_load_p<NT>(Pb, chunk_bytes, voff0, tl);
+    for (int tl = 0; tl < REC_RING; ++tl) pq[tl] = rec_load_p<NT>(Pb, chunk_bytes, voff0, tl);
     float aq[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) aq[0][i] = ul[(i * NT + 0) * 64];
