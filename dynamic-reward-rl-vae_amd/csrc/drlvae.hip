@@ -79,6 +79,7 @@ struct drl_ctx {
     int comm_rank = 0, comm_size = 0;
     bool force_generic = false;   // DRLVAE_FORCE_GENERIC=1: explicit-state batches always take the fallback kernel (tests)
     int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
+    int gemv_rounds = 3;          // estimator.predict batches of up to this many states per CU take the matrix-vector kernel (DRLVAE_GEMV_ROUNDS)
     int rec2_mode = 1;            // two candidate states in one wave: 0 never, 1 whole rounds of tiles, 2 always (DRLVAE_REC2)
     bool last_overlap = false;
     std::string err;
@@ -400,6 +401,7 @@ int drl_create(int device_id, drl_ctx** out) {
     if (const char* e = getenv("DRLVAE_FORCE_GENERIC")) c->force_generic = atoi(e) != 0;
     if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
     if (const char* e = getenv("DRLVAE_REC2")) c->rec2_mode = atoi(e);
+    if (const char* e = getenv("DRLVAE_GEMV_ROUNDS")) c->gemv_rounds = std::max(0, atoi(e));
     *out = c;
     return DRL_OK;
 }
@@ -1108,7 +1110,12 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     const size_t nb = (size_t)B * W * I * sizeof(float), qb = (size_t)B * A * sizeof(float);
     const int gv_rows = 32 * c->lstm.NT, gv_ip = (I + 3) & ~3;
     const size_t gv_lds = ((size_t)W * gv_ip + (size_t)W * gv_rows) * sizeof(float);
-    const bool gemv = B <= 4 && W <= GEMV_WMAX && gv_lds <= 150 * 1024;
+    // One workgroup per state.  The MFMA kernels need a 25-step chain of whole tiles however few the
+    // states (~140 us for the univariate net, more for wide inputs), a matrix-vector workgroup ~35 us,
+    // so it wins up to gemv_rounds (3) states per CU: the per-step call (1-4 states) and a replay batch
+    // alike (tools/predict_batch_sweep.py).
+    const long long gemv_max = c->force_generic ? 4 : std::max<long long>(4, (long long)c->gemv_rounds * c->n_cu);
+    const bool gemv = B <= gemv_max && W <= GEMV_WMAX && gv_lds <= 150 * 1024;
     // the matrix-vector kernel stages its state into LDS in one pass and writes A floats: it can work
     // on mapped host memory directly
     const bool direct = gemv && up16(nb) + qb <= PIN_IO_MAX;

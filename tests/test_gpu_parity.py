@@ -203,23 +203,35 @@ def test_edge_cases_ragged_short_series(scorer, ckpt_a1):
 
 
 # ----------------------------------------------------------------------------------- call surface
-_fallback = []
+_env_scorers = {}
+
+
+def _env_scorer(var, value):
+    """A further context created with an environment override (read at drl_create)."""
+    key = (var, value)
+    if key not in _env_scorers:
+        from drlvae.scorer import WindowScorer
+        old = os.environ.get(var)
+        os.environ[var] = value
+        try:
+            _env_scorers[key] = WindowScorer(0)
+        finally:
+            if old is None:
+                del os.environ[var]
+            else:
+                os.environ[var] = old
+    return _env_scorers[key]
 
 
 def _fallback_scorer():
-    """A second context created with DRLVAE_FORCE_GENERIC=1 (read at drl_create)."""
-    if not _fallback:
-        from drlvae.scorer import WindowScorer
-        old = os.environ.get("DRLVAE_FORCE_GENERIC")
-        os.environ["DRLVAE_FORCE_GENERIC"] = "1"
-        try:
-            _fallback.append(WindowScorer(0))
-        finally:
-            if old is None:
-                del os.environ["DRLVAE_FORCE_GENERIC"]
-            else:
-                os.environ["DRLVAE_FORCE_GENERIC"] = old
-    return _fallback[0]
+    """DRLVAE_FORCE_GENERIC=1: explicit-state batches take the fallback kernel."""
+    return _env_scorer("DRLVAE_FORCE_GENERIC", "1")
+
+
+def _mfma_scorer():
+    """DRLVAE_GEMV_ROUNDS=0: only batches of up to 4 states take the matrix-vector kernel (by default
+    up to 3 states per CU do), so that replay-sized batches reach the MFMA kernels."""
+    return _env_scorer("DRLVAE_GEMV_ROUNDS", "0")
 
 
 def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
@@ -228,9 +240,13 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     scorer.set_lstm(lstm)
     v = a1["series"][3]
     S = orc.states_list_univariate(v, W)[:300]
-    q = scorer.q_predict(S)
-    assert scorer.lstm_variant == "h128i2"              # explicit states through the register-stationary kernel
+    mf = _mfma_scorer()
+    mf.set_lstm(lstm)
+    q = mf.q_predict(S)
+    assert mf.lstm_variant == "h128i2"                  # explicit states through the register-stationary kernel
     assert_q_close(q, orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
+    qv = scorer.q_predict(S)                            # 300 states: one matrix-vector workgroup each by default
+    assert scorer.lstm_variant == "gemv" and np.array_equal(qv.view(np.uint32), q.view(np.uint32))
     one = scorer.q_predict(S[:1])                       # the reference's batch-1 call pattern
     assert scorer.lstm_variant == "gemv"           # matrix-vector kernel, same accumulation order:
     assert np.array_equal(one.view(np.uint32), q[:1].view(np.uint32))     # bit-identical to the MFMA kernel
@@ -238,7 +254,7 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
         few = scorer.q_predict(S[10:10 + bsz])
         assert scorer.lstm_variant == "gemv"
         assert np.array_equal(few.view(np.uint32), q[10:10 + bsz].view(np.uint32))
-    assert np.array_equal(scorer.q_predict(S[:5]).view(np.uint32), q[:5].view(np.uint32)) and scorer.lstm_variant == "h128i2"
+    assert np.array_equal(mf.q_predict(S[:5]).view(np.uint32), q[:5].view(np.uint32)) and mf.lstm_variant == "h128i2"
     # the same states scored as sliding windows of the series give the same bits
     slid = scorer.score(v, W, flag_mode="quirk", want=("q",))["q"][:300]
     assert np.array_equal(slid.view(np.uint32), q.view(np.uint32))
@@ -247,16 +263,21 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     big = rng.random((8192 + 700, W, 2), dtype=np.float32)
     big[:, :, 1] = (big[:, :, 1] < 0.3)
     qb = scorer.q_predict(big)
+    assert scorer.lstm_variant == "h128i2" and scorer.lstm_tile == 64
     head = scorer.q_predict(big[:512])                  # 2 x 256 next-states of a DQN update
-    assert np.array_equal(head.view(np.uint32), qb[:512].view(np.uint32))
-    tail = scorer.q_predict(big[-700:])
+    assert scorer.lstm_variant == "gemv" and np.array_equal(head.view(np.uint32), qb[:512].view(np.uint32))
+    head = mf.q_predict(big[:512])                      # the same through 16-window MFMA tiles
+    assert mf.lstm_tile == 16 and np.array_equal(head.view(np.uint32), qb[:512].view(np.uint32))
+    tail = mf.q_predict(big[-700:])
     assert np.array_equal(tail.view(np.uint32), qb[-700:].view(np.uint32))
     assert_q_close(head, orc.lstm_q(big[:512], lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], dtype=np.float64))
     # other shapes keep the generic kernel
     lstm64 = synth_lstm(rng, 2, 64)
     scorer.set_lstm(lstm64)
-    q64 = scorer.q_predict(S[:64])
-    assert scorer.lstm_variant == "xproj+rec"
+    mf.set_lstm(lstm64)
+    q64 = mf.q_predict(S[:64])
+    assert mf.lstm_variant == "xproj+rec"
+    assert np.array_equal(scorer.q_predict(S[:64]).view(np.uint32), q64.view(np.uint32)) and scorer.lstm_variant == "gemv"
     assert_q_close(q64, orc.lstm_q(S[:64], lstm64["kernel"], lstm64["bias"], lstm64["w_out"], lstm64["b_out"], dtype=np.float64))
     two = scorer.q_predict(S[5:7])
     assert scorer.lstm_variant == "gemv" and np.array_equal(two.view(np.uint32), q64[5:7].view(np.uint32))
@@ -267,8 +288,10 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
         scorer.set_lstm(lm)
         st = rng.normal(size=(40, W, F_ + 1)).astype(np.float32)
         st[:, :, F_] = (st[:, :, F_] > 0)
-        qg = scorer.q_predict(st)
-        assert scorer.lstm_variant == ("xproj+rec" if H_ <= 64 else "xproj+h128")
+        mf.set_lstm(lm)
+        qg = mf.q_predict(st)
+        assert mf.lstm_variant == ("xproj+rec" if H_ <= 64 else "xproj+h128")
+        assert np.array_equal(scorer.q_predict(st).view(np.uint32), qg.view(np.uint32)) and scorer.lstm_variant == "gemv"
         assert_q_close(qg, orc.lstm_q(st, lm["kernel"], lm["bias"], lm["w_out"], lm["b_out"], dtype=np.float64))
         fb = _fallback_scorer()
         fb.set_lstm(lm)
