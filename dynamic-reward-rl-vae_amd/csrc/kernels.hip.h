@@ -1499,9 +1499,21 @@ __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
     float* s_zx = gv_smem + W * IP;             // [W][ROWS]: input part of every step's pre-activations
     {
         const float* __restrict__ x = a.x + (long long)b * a.win_stride;
-        for (int e = r; e < W * IP; e += ROWS) {
-            const int t = e / IP, f = e - t * IP;
-            s_x[e] = f < I ? x[(long long)t * a.row_stride + f] : 0.0f;
+        // eight elements per thread in flight (the state may sit in mapped host memory: one round trip
+        // per batch of loads, not per element)
+        const int n = W * IP;
+        for (int e0 = r; e0 < n; e0 += 8 * ROWS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * ROWS < n ? e0 + u * ROWS : n - 1;
+                const int t = e / IP, f = e - t * IP;
+                v[u] = x[(long long)t * a.row_stride + (f < I ? f : I - 1)];
+                v[u] = f < I ? v[u] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * ROWS < n) s_x[e0 + u * ROWS] = v[u];
         }
         if (r < HP) { s_h[0][r] = 0.0f; s_h[1][r] = 0.0f; }
     }
@@ -1511,35 +1523,60 @@ __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
         const int kk = (u >> 3) * 4 + ((u & 7) >> 1), half = u & 1;
         U[u] = a.u[((size_t)kk * NT + tau) * 64 + half * 32 + i];
     }
-    const float bias = a.bias[(tau * 2 + ((i >> 2) & 1)) * 16 + (i & 3) + 4 * (i >> 3)];
     __syncthreads();
 
-    // input part: zx[t] = bias + sum_f wx[f] * x[t][f], f ascending; four features per pass
-    {
-        float zx[GEMV_WMAX];
+    // input part: zx[t] = bias + sum_f wx[f] * x[t][f], f ascending — a [rows x I] x [I x W] product, so
+    // it runs on the MFMA (columns = the W rows of the state; the chain of k-steps is the same sum in
+    // the same order): wave w takes gate tiles w, w + waves, ...; A fragments are the packed wx as it is.
+    // (Narrow inputs — the univariate [value, flag] — stay on the VALU: one pass of four features, no
+    // MFMA latency, no second barrier; 2 us of a 35 us kernel.)
+    if (I <= 4) {
+        const float bias = a.bias[(tau * 2 + ((i >> 2) & 1)) * 16 + (i & 3) + 4 * (i >> 3)];
+        float w[4];
 #pragma unroll
-        for (int t = 0; t < GEMV_WMAX; ++t) zx[t] = bias;
-        for (int f0 = 0; f0 < IP; f0 += 4) {
-            float w[4];
+        for (int q = 0; q < 4; ++q)             // wx is packed [ceil(I/2)][NT][64]: (f>>1, tau, (f&1)*32 + i); zero beyond I
+            w[q] = q < I ? a.wx[((size_t)(q >> 1) * NT + tau) * 64 + (q & 1) * 32 + i] : 0.0f;
+        for (int t = 0; t < W; ++t) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(s_x + t * IP);
+            float z = bias;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int f = f0 + q;           // wx is packed [ceil(I/2)][NT][64]: (f>>1, tau, (f&1)*32 + i); zero beyond I
-                w[q] = f < I ? a.wx[((size_t)(f >> 1) * NT + tau) * 64 + (f & 1) * 32 + i] : 0.0f;
-            }
+            for (int q = 0; q < 4; ++q)
+                if (q < I) z = fmaf(w[q], xv[q], z);
+            s_zx[t * ROWS + r] = z;
+        }
+    } else {
+        const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+        const int nks = (I + 1) >> 1;
+        for (int c0 = 0; c0 < W; c0 += 32) {                 // 32 rows of the state per pass (W <= 64: two)
+            const int t = c0 + j;
+            const float* __restrict__ xrow = s_x + (t < W ? t : W - 1) * IP + half;   // x[t][2*ks + half]
+            for (int tl = threadIdx.x >> 6; tl < NT; tl += ROWS / 64) {
+                f32x16 acc = load_bias16(a.bias, tl, half);
+                for (int ks0 = 0; ks0 < nks; ks0 += 16) {     // 16 fragments requested together
+                    float av[16], bv[16];
 #pragma unroll
-            for (int t = 0; t < GEMV_WMAX; ++t) {
+                    for (int u = 0; u < 16; ++u) {
+                        av[u] = 0.0f; bv[u] = 0.0f;
+                        if (ks0 + u < nks) {                      // wave-uniform
+                            av[u] = a.wx[((size_t)(ks0 + u) * NT + tl) * 64 + lane];
+                            bv[u] = xrow[2 * (ks0 + u)];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const bool live = ks0 + u < nks;          // wave-uniform
+                        const float b = (live && 2 * (ks0 + u) + half < I) ? bv[u] : 0.0f;
+                        if (live) acc = mfma32(av[u], b, acc);
+                    }
+                }
                 if (t < W) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(s_x + t * IP + f0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (f0 + q < I) zx[t] = fmaf(w[q], xv[q], zx[t]);
+                    for (int rr = 0; rr < 16; ++rr) s_zx[t * ROWS + tl * 32 + rowmap(rr, half)] = acc[rr];
                 }
             }
         }
-#pragma unroll
-        for (int t = 0; t < GEMV_WMAX; ++t)
-            if (t < W) s_zx[t * ROWS + r] = zx[t];          // read back by this thread only
     }
+    __syncthreads();                                          // zx rows are read by other waves' threads
 
     float c = 0.0f;
     for (int t = 0; t < W; ++t) {
