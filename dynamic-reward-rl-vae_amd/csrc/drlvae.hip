@@ -1043,7 +1043,8 @@ int drl_vae_predict(drl_ctx* c, const float* x, int64_t B, const float* eps, flo
     const size_t nb = (size_t)B * D * sizeof(float), eb = (size_t)B * sizeof(float);
     const size_t nz = eps ? (size_t)B * c->vae.latent * sizeof(float) : 0;
     // the reference's per-step call (one window): inputs and outputs in mapped host memory, no copies
-    const bool direct = B <= 32 && 2 * up16(nb) + up16(eb) + up16(nz) <= PIN_IO_MAX;
+    // (narrow windows only: a wide window is read tile by tile, one PCIe round trip each)
+    const bool direct = B <= 32 && D <= 128 && 2 * up16(nb) + up16(eb) + up16(nz) <= PIN_IO_MAX;
     const float *d_x, *d_eps = nullptr;
     float *d_rec, *d_err;
     if (direct) {

@@ -272,15 +272,44 @@ __global__ __launch_bounds__(256, (LDSW ? 1 : (MAXT <= 2 ? 3 : 1))) void vae_ker
 #pragma unroll
         for (int ot = 0; ot < MAXT; ++ot)
             cur[ot] = ot < nout ? load_bias16(wp(a.b[0]), ot, half) : f32x16{};
-        for (int it = 0; it < nin; ++it) {
-            float bv[16];
-            vae_input16(a, xin, it, half, has_norm, sc, of, bv);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+        if constexpr (MAXT > 2) {
+            // wide layers (explicit batches of wide windows: nin up to ~100 tiles, one wave alone with the L2
+            // latency): the A fragments and inputs of tile it+1 are requested before the MFMAs of tile it
+            float wa[MAXT * 16], bv[16];
+            auto load_tile = [&](int it, float (&wt)[MAXT * 16], float (&bt)[16]) {
 #pragma unroll
                 for (int ot = 0; ot < MAXT; ++ot)
-                    if (ot < nout)
-                        cur[ot] = mfma32(w[(((size_t)it * nout + ot) * 16 + r) * 64 + lane], bv[r], cur[ot]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        wt[ot * 16 + r] = w[(((size_t)it * nout + (ot < nout ? ot : nout - 1)) * 16 + r) * 64 + lane];
+                vae_input16(a, xin, it, half, has_norm, sc, of, bt);
+            };
+            load_tile(0, wa, bv);
+            for (int it = 0; it < nin; ++it) {
+                float wn[MAXT * 16], bn[16];
+                load_tile(it + 1 < nin ? it + 1 : it, wn, bn);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                    for (int ot = 0; ot < MAXT; ++ot)
+                        if (ot < nout) cur[ot] = mfma32(wa[ot * 16 + r], bv[r], cur[ot]);
+                }
+#pragma unroll
+                for (int q = 0; q < MAXT * 16; ++q) wa[q] = wn[q];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bv[q] = bn[q];
+            }
+        } else {
+            for (int it = 0; it < nin; ++it) {
+                float bv[16];
+                vae_input16(a, xin, it, half, has_norm, sc, of, bv);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                    for (int ot = 0; ot < MAXT; ++ot)
+                        if (ot < nout)
+                            cur[ot] = mfma32(w[(((size_t)it * nout + ot) * 16 + r) * 64 + lane], bv[r], cur[ot]);
+                }
             }
         }
 #pragma unroll
@@ -334,17 +363,35 @@ __global__ __launch_bounds__(256, (LDSW ? 1 : (MAXT <= 2 ? 3 : 1))) void vae_ker
         const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
         const float* __restrict__ w = wp(a.w[p]);
         float sq = 0.0f;
+        float wa[MAXT > 2 ? MAXT * 16 : 1], wn[MAXT > 2 ? MAXT * 16 : 1];
+        auto load_out_tile = [&](int ot, float (&wt)[MAXT > 2 ? MAXT * 16 : 1]) {
+            if constexpr (MAXT > 2) {
+#pragma unroll
+                for (int it = 0; it < MAXT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        wt[it * 16 + r] = w[(((size_t)ot * nin + (it < nin ? it : nin - 1)) * 16 + r) * 64 + lane];
+            }
+        };
+        load_out_tile(0, wa);
         for (int ot = 0; ot < nout; ++ot) {
             f32x16 acc = load_bias16(wp(a.b[p]), ot, half);
             float xv16[16];                              // requested before the MFMAs that hide them
             vae_input16(a, xin, ot, half, has_norm, sc, of, xv16);
+            load_out_tile(ot + 1 < nout ? ot + 1 : ot, wn);      // wide layers: next tile's fragments in flight
 #pragma unroll
             for (int it = 0; it < MAXT; ++it) {
                 if (it < nin) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], acc);
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (MAXT > 2) acc = mfma32(wa[it * 16 + r], cur[it][r], acc);
+                        else acc = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], acc);
+                    }
                 }
+            }
+            if constexpr (MAXT > 2) {
+#pragma unroll
+                for (int q = 0; q < MAXT * 16; ++q) wa[q] = wn[q];
             }
             act16(acc, a.act[p]);
 #pragma unroll
