@@ -79,7 +79,8 @@ struct drl_ctx {
     int comm_rank = 0, comm_size = 0;
     bool force_generic = false;   // DRLVAE_FORCE_GENERIC=1: explicit-state batches always take the fallback kernel (tests)
     int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
-    int gemv_rounds = 3;          // estimator.predict batches of up to this many states per CU take the matrix-vector kernel (DRLVAE_GEMV_ROUNDS)
+    int gemv_rounds = -1;         // estimator.predict batches of up to this many states per CU take the matrix-vector kernel
+                                  // (DRLVAE_GEMV_ROUNDS; -1: 4 for the univariate H > 64 net, 8 for the others)
     int rec2_mode = 1;            // two candidate states in one wave: 0 never, 1 whole rounds of tiles, 2 always (DRLVAE_REC2)
     bool last_overlap = false;
     std::string err;
@@ -1113,9 +1114,12 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
     const size_t gv_lds = ((size_t)W * gv_ip + (size_t)W * gv_rows) * sizeof(float);
     // One workgroup per state.  The MFMA kernels need a 25-step chain of whole tiles however few the
     // states (~140 us for the univariate net, more for wide inputs), a matrix-vector workgroup ~35 us,
-    // so it wins up to gemv_rounds (3) states per CU: the per-step call (1-4 states) and a replay batch
-    // alike (tools/predict_batch_sweep.py).
-    const long long gemv_max = c->force_generic ? 4 : std::max<long long>(4, (long long)c->gemv_rounds * c->n_cu);
+    // so it wins for the per-step call (1-4 states) and for a replay batch alike.  Measured hand-over
+    // (tools/predict_batch_sweep.py): the univariate net, whose MFMA kernel needs no projection pass, at
+    // 4 states per CU (1,024: 144 against 175 us; 1,280: 198 against 162 us); the projection paths
+    // later (I=39/H=128 at about 2,000 states, WaDi's I=124/H=64 not before 1,536) — 8 per CU there.
+    const int rounds = c->gemv_rounds >= 0 ? c->gemv_rounds : (I == 2 && c->lstm.NT == 16) ? 4 : 8;
+    const long long gemv_max = c->force_generic ? 4 : std::max<long long>(4, (long long)rounds * c->n_cu);
     const bool gemv = B <= gemv_max && W <= GEMV_WMAX && gv_lds <= 150 * 1024;
     // the matrix-vector kernel stages its state into LDS in one pass and writes A floats: it can work
     // on mapped host memory directly

@@ -11,7 +11,7 @@ sc = WindowScorer(0)
 rng = np.random.default_rng(0)
 for I, H in ((2, 128), (124, 64), (39, 128)):
     sc.set_lstm(synth_lstm(rng, I, H))
-    for B in (1, 5, 64, 256, 512, 768, 1024, 4096):
+    for B in ([int(b) for b in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 5, 64, 256, 512, 768, 1024, 4096)):
         s = rng.random((B, 25, I), dtype=np.float32)
         for _ in range(5): sc.q_predict(s)
         t0 = time.perf_counter()
