@@ -672,9 +672,8 @@ namespace {
 struct OptDev {
     const float* in_scale = nullptr;
     const float* in_offset = nullptr;
-    const float* center = nullptr;
-    const float* scale = nullptr;
-    const float* inv_scale = nullptr;
+    const float* rs = nullptr;      // RobustScaler table [4][P]: c_hi | c_lo | inv_hi | inv_lo
+    int rsP = 0;
 };
 
 // Uploads the small host-side option arrays (per series / per flattened column).  They are gathered
@@ -686,18 +685,28 @@ int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d
     if (o->vae_center && !o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
     if (!o->in_scale && !o->vae_center) return DRL_OK;
     const size_t S = o->in_scale ? up16(n_seg) : 0;
-    const size_t P = o->vae_center ? up32(D) : 0;      // padded to a whole 32-feature tile (center 0, scale 1):
-    std::vector<float> h(2 * S + 3 * P, 0.0f);          // vae_wide_kernel streams them per tile
+    const size_t P = o->vae_center ? up32(D) : 0;      // padded to a whole 32-feature tile (center 0, 1/scale 1):
+    std::vector<float> h(2 * S + 4 * P, 0.0f);          // vae_wide_kernel streams them per tile
     if (S) {
         memcpy(h.data(), o->in_scale, n_seg * sizeof(float));
         memcpy(h.data() + S, o->in_offset, n_seg * sizeof(float));
     }
+    // center_ and 1/scale_ as float32 hi + lo pairs of the caller's float64 values (robust_apply, kernels.hip.h)
     float* hc = h.data() + 2 * S;
     for (size_t i = 0; i < P; ++i) {
         const bool in = i < (size_t)D;
-        hc[i] = in ? o->vae_center[i] : 0.0f;
-        hc[P + i] = in ? o->vae_scale[i] : 1.0f;
-        hc[2 * P + i] = in ? (float)(1.0 / (double)o->vae_scale[i]) : 1.0f;
+        const double cen = in ? o->vae_center[i] : 0.0;
+        const double scl = in ? o->vae_scale[i] : 1.0;
+        if (in && !(std::isfinite(cen) && std::isfinite(scl) && scl != 0.0))
+            return fail(c, DRL_ERR_ARG, "opts.vae_center/vae_scale[%zu] must be finite, scale non-zero", i);
+        const double inv = 1.0 / scl;
+        const float c_hi = (float)cen, i_hi = (float)inv;
+        if (!std::isfinite(c_hi) || !std::isfinite(i_hi))
+            return fail(c, DRL_ERR_ARG, "opts.vae_center/vae_scale[%zu] outside the float32 range", i);
+        hc[i] = c_hi;
+        hc[P + i] = (float)(cen - (double)c_hi);
+        hc[2 * P + i] = i_hi;
+        hc[3 * P + i] = (float)(inv - (double)i_hi);
     }
     if (!(c->opt.p && c->opt_S == S && c->opt_P == P && c->opt_host.size() == h.size() &&
           memcmp(c->opt_host.data(), h.data(), h.size() * sizeof(float)) == 0)) {
@@ -710,7 +719,7 @@ int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d
     }
     const float* base = (const float*)c->opt.p;
     if (S) { d.in_scale = base; d.in_offset = base + S; }
-    if (P) { d.center = base + 2 * S; d.scale = base + 2 * S + P; d.inv_scale = base + 2 * S + 2 * P; }
+    if (P) { d.rs = base + 2 * S; d.rsP = (int)P; }
     return DRL_OK;
 }
 
@@ -768,11 +777,11 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         memset(&a, 0, sizeof a);
         fill_vae_args(c, a);
         a.x = d_series; a.win_stride = F; a.lag_elems = (1 - o->vae_lag) * F; a.D = W * F;
-        a.center = od.center; a.scale = od.scale; a.inv_scale = od.inv_scale; a.clip = o->vae_clip;
+        a.rs = od.rs; a.rsP = od.rsP; a.clip = o->vae_clip;
         a.eps = d_eps; a.seg = seg; a.n_tiles = sh.tiles32; a.err = d_err; a.recon = nullptr;
         // wide windows: stream the first/last layer through LDS when the windows' flat region fits
         const int xr_floats = (31 * F + ((W * F + 31) & ~31) + 3) & ~3;
-        const size_t wide_lds = ((size_t)2 * VW_WT + 256 + (size_t)4 * xr_floats) * sizeof(float);
+        const size_t wide_lds = ((size_t)2 * VW_WT + 2 * VW_SIDE + (size_t)4 * xr_floats) * sizeof(float);
         const bool wide = W * F > 128 && !d_eps && wide_lds <= 160 * 1024 &&
                           c->vae.dout[0] > 96 && c->vae.dout[0] <= 128 &&
                           c->vae.din[c->vae.n_path - 1] > 96 && c->vae.din[c->vae.n_path - 1] <= 128;
@@ -786,7 +795,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 c->wide_lds_set = 160 * 1024;
             }
             const dim3 grid((sh.tiles32 + 3) / 4);
-            if (a.center) hipLaunchKernelGGL(vae_wide_kernel<true>, grid, dim3(256), wide_lds, vst, a, xr_floats);
+            if (a.rs) hipLaunchKernelGGL(vae_wide_kernel<true>, grid, dim3(256), wide_lds, vst, a, xr_floats);
             else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, vst, a, xr_floats);
             c->last_vae_variant = "wide";
         } else {

@@ -122,6 +122,21 @@ __device__ __forceinline__ float minmax_apply(float x, float sc, float of) {
     return m + of;
 }
 
+// reference myasp-wadi.py:138-139 (sklearn RobustScaler.transform on the float32 windows, then np.clip):
+//   X -= center_   numpy rounds x - center_ to float32 once,
+//   X /= scale_    then t / scale_ (float64 scale_) to float32 once.
+// center_ and 1/scale_ arrive as float32 hi+lo pairs of the caller's float64 parameters.  x - c_hi is
+// exact whenever the two are within a factor of two of each other (Sterbenz) — the cancelling case, where
+// a center truncated to float32 would cost |c_lo|/scale_ — so (x - c_hi) - c_lo is the float32 rounding
+// of x - center_ there, and within an ulp of it elsewhere; t*inv_hi + t*inv_lo with one fma is the
+// float32 rounding of t/scale_ up to a 2^-48 relative term.  ONE formula for every kernel.
+__device__ __forceinline__ float robust_apply(float x, float c_hi, float c_lo, float i_hi, float i_lo, float clip) {
+    float t = x - c_hi;
+    t = t - c_lo;
+    const float p = t * i_lo;
+    return __builtin_amdgcn_fmed3f(fmaf(t, i_hi, p), -clip, clip);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: VAE mean path + reconstruction error.  One wave = 32 windows, no LDS, no barriers.
 struct VaeArgs {
@@ -141,9 +156,11 @@ struct VaeArgs {
     long long win_stride;                    // elements between consecutive windows (F, or D)
     int lag_elems;                           // element offset of window 0 inside its series: (1-lag)*F
     int D;                                   // window length in elements (W*F)
-    const float* center;                     // [D] or null (RobustScaler)
-    const float* scale;                      // [D]
-    const float* inv_scale;                  // [D] 1/scale (wide kernel)
+    // RobustScaler (reference myasp-wadi.py:138): per flattened column, padded to P = a multiple of 32
+    // columns, [4][P] = c_hi | c_lo | inv_hi | inv_lo with center_ = c_hi + c_lo and 1/scale_ = inv_hi +
+    // inv_lo split from the caller's float64 parameters on the host (pad: 0 | 0 | 1 | 0); null = none
+    const float* rs;
+    int rsP;
     float clip;                              // <= 0: none
     const float* eps;                        // [K_total, latent] or null
     SegTab seg;
@@ -205,15 +222,16 @@ __device__ __forceinline__ void vae_input16(const VaeArgs& a, const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = minmax_apply(bv[r], sc, of);
     }
-    if (a.center) {
-        float ce[16], sv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { ce[r] = a.center[dc[r]]; sv[r] = a.scale[dc[r]]; }
+    if (a.rs) {
+        const float clip = a.clip > 0.0f ? a.clip : 3.0e38f;
+        float ch[16], cl[16], ih[16], il[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            bv[r] = (bv[r] - ce[r]) / sv[r];
-            if (a.clip > 0.0f) bv[r] = fminf(fmaxf(bv[r], -a.clip), a.clip);
+            ch[r] = a.rs[dc[r]]; cl[r] = a.rs[a.rsP + dc[r]];
+            ih[r] = a.rs[2 * a.rsP + dc[r]]; il[r] = a.rs[3 * a.rsP + dc[r]];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = robust_apply(bv[r], ch[r], cl[r], ih[r], il[r], clip);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) bv[r] = (it * 32 + rowmap(r, half)) < a.D ? bv[r] : 0.0f;
@@ -442,16 +460,16 @@ __device__ __forceinline__ void vw_stage_store(const f32x4 (&reg)[4], float* dst
 #pragma unroll
     for (int i = 0; i < 4; ++i) p[i * 256] = reg[i];
 }
-// side tile of feature tile `ft`: center[32] | inv_scale[32] | packed bias[32].  Every thread owns
-// one stream (a base pointer chosen once, advanced 32 floats per tile) so the per-tile load is a
-// single unconditional global_load: center/inv_scale are padded to a multiple of 32 on the host
-// (pad: center 0, inv_scale 1) and the packed bias is tile-padded by construction.  Threads with
-// nothing to fetch re-read a valid dummy word.
+// side tile of feature tile `ft`: c_hi[32] | c_lo[32] | inv_hi[32] | inv_lo[32] | packed bias[32].
+// Every thread owns one stream (a base pointer chosen once, advanced 32 floats per tile) so the
+// per-tile load is a single unconditional global_load: the scaler table is padded to a multiple of 32
+// columns on the host and the packed bias is tile-padded by construction.  Threads with nothing to
+// fetch re-read a valid dummy word.
+#define VW_SIDE 160
 __device__ __forceinline__ const float* vw_side_stream(const VaeArgs& a, const float* __restrict__ bias_p, bool scaled) {
     const int t = threadIdx.x;
-    if (scaled && t < 32) return a.center + t;
-    if (scaled && t < 64) return a.inv_scale + (t - 32);
-    if (bias_p && t >= 64 && t < 96) return bias_p + (t - 64);
+    if (scaled && t < 128) return a.rs + (size_t)(t >> 5) * a.rsP + (t & 31);
+    if (bias_p && t >= 128 && t < 160) return bias_p + (t - 128);
     return a.w[0];
 }
 
@@ -464,13 +482,13 @@ __device__ __forceinline__ const float* vw_side_stream(const VaeArgs& a, const f
 #endif
 // Last-layer epilogue of one 32-feature output tile: activation, input transform, squared error.
 template <bool SCALED, int ACT, bool MASKED>
-__device__ __forceinline__ float vw_epilogue(const f32x16& acc, const float (&xv)[16], const float (&cen)[16],
-                                             const float (&isc)[16], float clip, int d0, int D, int half, float sq) {
+__device__ __forceinline__ float vw_epilogue(const f32x16& acc, const float (&xv)[16], const float (&rsv)[4][16],
+                                             float clip, int d0, int D, int half, float sq) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float y = apply_act(acc[r], ACT);
         float x = xv[r];
-        if (SCALED) x = __builtin_amdgcn_fmed3f((x - cen[r]) * isc[r], -clip, clip);
+        if (SCALED) x = robust_apply(x, rsv[0][r], rsv[1][r], rsv[2][r], rsv[3][r], clip);
         float df = y - x;
         if (MASKED) df = (d0 + rowmap(r, half) < D) ? df : 0.0f;      // the feature tail of the last tile is padding
         sq = fmaf(df, df, sq);
@@ -482,10 +500,10 @@ template <bool SCALED>
 __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArgs a, int xr_floats) {
     extern __shared__ __attribute__((aligned(16))) float vw_smem[];
     float* wt = vw_smem;                         // [2][VW_WT]
-    float* side = vw_smem + 2 * VW_WT;           // [2][128]
+    float* side = vw_smem + 2 * VW_WT;           // [2][VW_SIDE]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, j = lane & 31;
-    float* xr = vw_smem + 2 * VW_WT + 256 + (size_t)wave * xr_floats;
+    float* xr = vw_smem + 2 * VW_WT + 2 * VW_SIDE + (size_t)wave * xr_floats;
     const int tile = blockIdx.x * 4 + wave;
     const bool active = tile < a.n_tiles;        // wave-uniform; idle waves still stage and sync
     const float clip = a.clip > 0.0f ? a.clip : 3.0e38f;
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
         const float* __restrict__ ss = vw_side_stream(a, nullptr, SCALED);
         vw_stage_load(stg, w);
         vw_stage_store(stg, wt);
-        if (threadIdx.x < 128) side[threadIdx.x] = ss[0];
+        if (threadIdx.x < VW_SIDE) side[threadIdx.x] = ss[0];
         __syncthreads();
         for (int it = 0; it < nin; ++it) {
             const int cb = it & 1;
@@ -543,20 +561,20 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
             }
             if (active) {
                 const float* __restrict__ wb = wt + cb * VW_WT + lane;
-                const float* __restrict__ sb = side + cb * 128;
+                const float* __restrict__ sb = side + cb * VW_SIDE;
                 const float* __restrict__ xt = xw + it * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dl = rowmap(r, half);
                     float bv = xt[dl];
-                    if (SCALED && VW_ABL != 5) bv = __builtin_amdgcn_fmed3f((bv - sb[dl]) * sb[32 + dl], -clip, clip);
+                    if (SCALED && VW_ABL != 5) bv = robust_apply(bv, sb[dl], sb[32 + dl], sb[64 + dl], sb[96 + dl], clip);
 #pragma unroll
                     for (int ot = 0; ot < 4; ++ot) cur[ot] = mfma32(wb[(ot * 16 + r) * 64], bv, cur[ot]);
                 }
             }
             if (more) {
                 vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
-                if (threadIdx.x < 128) side[(cb ^ 1) * 128 + threadIdx.x] = side_next;
+                if (threadIdx.x < VW_SIDE) side[(cb ^ 1) * VW_SIDE + threadIdx.x] = side_next;
             }
             VW_SYNC();
         }
@@ -599,7 +617,7 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
         const float* __restrict__ ss = vw_side_stream(a, a.b[p], SCALED);
         vw_stage_load(stg, w);
         vw_stage_store(stg, wt);
-        if (threadIdx.x < 128) side[threadIdx.x] = ss[0];
+        if (threadIdx.x < VW_SIDE) side[threadIdx.x] = ss[0];
         __syncthreads();
         for (int ot = 0; ot < nout; ++ot) {
             const int cb = ot & 1;
@@ -611,20 +629,20 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
             }
             if (active) {
                 const float* __restrict__ wb = wt + cb * VW_WT + lane;
-                const float* __restrict__ sb = side + cb * 128;
+                const float* __restrict__ sb = side + cb * VW_SIDE;
                 const float* __restrict__ xt = xw + ot * 32;
                 // everything the tile reads from LDS is requested before its first MFMA (bias first,
                 // it initialises the accumulator), so the LDS latency is paid once per tile and the
                 // epilogue's operands arrive under the MFMAs
-                f32x16 acc = load_bias16(sb + 64, 0, half);
-                float av[64], xv[16], cen[16], isc[16];
+                f32x16 acc = load_bias16(sb + 128, 0, half);
+                float av[64], xv[16], rsv[4][16];
 #pragma unroll
                 for (int i = 0; i < 64; ++i) av[i] = wb[i * 64];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dl = rowmap(r, half);
                     xv[r] = xt[dl];
-                    if (SCALED) { cen[r] = sb[dl]; isc[r] = sb[32 + dl]; }
+                    if (SCALED) { rsv[0][r] = sb[dl]; rsv[1][r] = sb[32 + dl]; rsv[2][r] = sb[64 + dl]; rsv[3][r] = sb[96 + dl]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -637,19 +655,19 @@ __global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArg
                 // activation code and "is this the padded last tile" are wave-uniform: one straight-line
                 // epilogue per combination, no per-element selects or copies
                 const bool masked = ot + 1 == nout;
-                if (act == 3) sq = masked ? vw_epilogue<SCALED, 3, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
-                                          : vw_epilogue<SCALED, 3, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
-                else if (act == 2) sq = masked ? vw_epilogue<SCALED, 2, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
-                                               : vw_epilogue<SCALED, 2, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
-                else if (act == 1) sq = masked ? vw_epilogue<SCALED, 1, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
-                                               : vw_epilogue<SCALED, 1, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
-                else sq = masked ? vw_epilogue<SCALED, 0, true>(acc, xv, cen, isc, clip, ot * 32, D, half, sq)
-                                 : vw_epilogue<SCALED, 0, false>(acc, xv, cen, isc, clip, ot * 32, D, half, sq);
+                if (act == 3) sq = masked ? vw_epilogue<SCALED, 3, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
+                                          : vw_epilogue<SCALED, 3, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
+                else if (act == 2) sq = masked ? vw_epilogue<SCALED, 2, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
+                                               : vw_epilogue<SCALED, 2, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
+                else if (act == 1) sq = masked ? vw_epilogue<SCALED, 1, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
+                                               : vw_epilogue<SCALED, 1, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
+                else sq = masked ? vw_epilogue<SCALED, 0, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
+                                 : vw_epilogue<SCALED, 0, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
 #endif
             }
             if (more) {
                 vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
-                if (threadIdx.x < 128) side[(cb ^ 1) * 128 + threadIdx.x] = side_next;
+                if (threadIdx.x < VW_SIDE) side[(cb ^ 1) * VW_SIDE + threadIdx.x] = side_next;
             }
             VW_SYNC();
         }

@@ -31,6 +31,18 @@ def minmax_params(x, dtype=np.float32):
     return scale, dtype(0.0) - mn * scale
 
 
+def minmax_normalise(x, dtype=np.float32) -> np.ndarray:
+    """The value column as the reference's environments hand it to the path: ``MinMaxScaler().
+    fit_transform`` — sklearn's ``x*scale_ + min_``, two roundings in ``dtype`` — then float32.
+    ``dtype=np.float32`` is env.py (cast at :75 precedes the scaling at :78-79; the device does the
+    same arithmetic itself when given ``in_scale``/``in_offset``); ``dtype=np.float64`` is
+    env_smd.py:76-77, 97 (scaled in float64, the frame cast to float32 afterwards): that variant
+    is host arithmetic here as it is in the reference — once per series at load time."""
+    x = np.asarray(x, dtype=dtype)
+    scale, off = minmax_params(x, dtype)
+    return (x * scale + off).astype(np.float32)
+
+
 # ------------------------------------------------------------------------------------------ weights
 
 
@@ -212,8 +224,9 @@ def update_dynamic_coef_proportional(current_coef, episode_reward, target_reward
 def penalty_array(values, n_steps: int, vae: KerasVAE, center=None, scale=None, clip: float = 10.0):
     """The module-level ``penalty_array`` of the WaDi driver (reference myasp-wadi.py:130-149):
     ``values`` (N, F) raw sensors -> float array (N,), zeros for the first n_steps-1 entries, then
-    the reconstruction error of the window ending at each sample (RobustScaler + clip applied on
-    the device)."""
+    the reconstruction error of the window ending at each sample.  ``center`` / ``scale`` are the
+    fitted ``RobustScaler``'s ``center_`` / ``scale_`` (they cross the C-ABI in float64 whatever their
+    dtype); the device applies sklearn's in-place float32 transform and the clip."""
     x = np.asarray(values, dtype=np.float32)
     if x.ndim == 1:
         x = x[:, None]

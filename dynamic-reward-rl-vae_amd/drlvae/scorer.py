@@ -128,8 +128,16 @@ class WindowScorer:
             o.eps = host(eps)
         o.in_scale = host(in_scale)
         o.in_offset = host(in_offset)
-        o.vae_center = host(vae_center)
-        o.vae_scale = host(vae_scale)
+        def host64(a):
+            # RobustScaler parameters cross the ABI in float64, as sklearn holds them (myasp-wadi.py:96)
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data
+
+        o.vae_center = host64(vae_center)
+        o.vae_scale = host64(vae_scale)
         o.vae_clip = float(vae_clip or 0.0)
         return o
 

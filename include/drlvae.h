@@ -74,8 +74,11 @@ typedef struct drl_score_opts {
                                 v = x*scale_ + min_, two float32 roundings); NULL = series is
                                 already normalised */
     const float* in_offset;  /* per-series min_ [n_seg]; required iff in_scale */
-    const float* vae_center; /* optional RobustScaler center_ [W*F] (reference myasp-wadi.py:138) */
-    const float* vae_scale;  /* RobustScaler scale_ [W*F]; required iff vae_center */
+    const double* vae_center;/* optional RobustScaler center_ [W*F], float64 as sklearn holds scale_ (and, for
+                                float64 training windows, center_): reference myasp-wadi.py:96, 138.  The
+                                device applies sklearn's in-place float32 transform: x - center_ rounded to
+                                float32, then / scale_ rounded to float32 (see robust_apply, kernels.hip.h) */
+    const double* vae_scale; /* RobustScaler scale_ [W*F], finite and non-zero; required iff vae_center */
     float vae_clip;          /* clip of the scaled VAE input (myasp-wadi.py:139); <= 0 = none */
     int32_t reserved;
 } drl_score_opts;

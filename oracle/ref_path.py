@@ -163,12 +163,26 @@ def vae_windows_univariate(v, W):
     return v[idx]
 
 
+def robust_scaler_transform(win, center, scale, clip=10.0):
+    """sklearn ``RobustScaler.transform`` on a float32 array followed by ``np.clip`` (reference
+    myasp-wadi.py:138-139).  sklearn keeps float32 input as float32 and works IN PLACE:
+    ``X -= center_`` then ``X /= scale_``.  With a float32 left-hand side numpy evaluates each of
+    the two in the wider of the operand types and rounds the result to float32 — two float32
+    roundings, not one — which is what the two in-place statements below do."""
+    win = np.array(win, dtype=np.float32, copy=True)
+    if center is not None:
+        win -= np.asarray(center)
+        win /= np.asarray(scale)
+    if clip is not None:
+        win = np.clip(win, -clip, clip)
+    return win
+
+
 def vae_windows_multivariate(x, W, center=None, scale=None, clip=10.0, k0=0, k1=None):
     """reference myasp-wadi.py:132-139 — windows i = W-1 .. N-1 of rows i-W+1..i, flattened
-    time-major (index t*F+f), RobustScaler ``(x-center_)/scale_`` per flattened column (float64
-    parameters applied to the float32 windows -> numpy promotes to float64), clip to +-clip.
-    The reference then feeds the float64 array to ``vae.predict`` which casts to float32.
-    Returns float32 (n, W*F); row j <-> window ending at sample j+W-1.
+    time-major (index t*F+f) as float32, ``scaler.transform`` (RobustScaler, per flattened column)
+    and ``np.clip``: see robust_scaler_transform.  Returns float32 (n, W*F); row j <-> window ending
+    at sample j+W-1.
     """
     x = np.asarray(x, dtype=np.float32)
     N, F = x.shape
@@ -176,21 +190,19 @@ def vae_windows_multivariate(x, W, center=None, scale=None, clip=10.0, k0=0, k1=
     k1 = n if k1 is None else k1
     idx = np.arange(k0, k1)[:, None] + np.arange(W)[None, :]
     win = x[idx].reshape(k1 - k0, W * F)
-    if center is not None:
-        win = (win - np.asarray(center, np.float64)) / np.asarray(scale, np.float64)
-    if clip is not None:
-        win = np.clip(win, -clip, clip)
-    return win.astype(np.float32)
+    return robust_scaler_transform(win, center, scale, clip)
 
 
 def robust_scaler_fit(windows):
-    """sklearn ``RobustScaler().fit`` (reference myasp-wadi.py:96): center_ = median,
-    scale_ = IQR(25,75) with zeros replaced by 1; float64."""
-    w = np.asarray(windows, dtype=np.float64)
-    center = np.median(w, axis=0)
-    q = np.percentile(w, [25.0, 75.0], axis=0)
+    """sklearn ``RobustScaler().fit`` (reference myasp-wadi.py:96) on the windows as they are
+    (float32 there, :90): ``center_ = np.nanmedian(X, axis=0)`` — the dtype of X — and
+    ``scale_`` = per-column ``np.nanpercentile(col, (25.0, 75.0))`` difference (float64), with
+    ranges below 10 eps replaced by 1 (``_handle_zeros_in_scale``)."""
+    w = np.asarray(windows)
+    center = np.nanmedian(w, axis=0)
+    q = np.transpose([np.nanpercentile(w[:, j], (25.0, 75.0)) for j in range(w.shape[1])])
     scale = q[1] - q[0]
-    scale[scale < 10 * np.finfo(np.float64).eps] = 1.0
+    scale[scale < 10 * np.finfo(scale.dtype).eps] = 1.0
     return center, scale
 
 

@@ -12,6 +12,10 @@ What is taken from the reference itself:
   * trained weights: read from the reference's checkpoint bundles / ``vae_model.h5`` with this
     repo's dependency-free readers (the files are data, loaded without executing anything);
   * the soft known-answer numbers: the committed ``exp/*performance.txt`` lines.
+  * RobustScaler windows (a-5): sklearn's own ``RobustScaler().fit / .transform`` — the library call
+    the reference makes (myasp-wadi.py:96-97, 138-139) — on float32 windows of WaDi-like sensors;
+  * SMD normalisation (a-1, float64 variant): by importing the reference's own ``env_smd.py`` on a
+    small synthetic sensor + label file pair this script writes to a temporary directory.
 What is NOT from the reference: the expected err/Q/action vectors, which come from this repo's
 oracle (oracle/ref_path.py) and serve as regression anchors (TensorFlow cannot run here).
 """
@@ -41,6 +45,7 @@ import env as ref_env  # noqa: E402  (the reference's env.py)
 YDIR = os.path.join(REF, "ydata-labeled-time-series-anomalies-v1_0")
 A1_RUN = "A1_LP_1500init_warmup_h128_b256_300ep_num_LP200_num_AL1000_d0.96"
 A2_RUN = "A2_LP_1500init_warmup_h128_b256_300ep_num_LP200_num_AL100_d0.96"
+SMD_RUN = "SMD_LP_1500init_warmup_h128_b256_30ep_num_LP200_num_AL1000_d0.96"
 
 
 def load_repo(subdir):
@@ -98,7 +103,88 @@ def save_model_npz(path, lstm, vae):
     np.savez_compressed(path, **d)
 
 
+def scaler_and_smd_fixtures():
+    """a-5 and the env_smd variant of a-1, pinned by running the library calls the reference makes."""
+    import tempfile
+    from sklearn.preprocessing import RobustScaler
+    import sklearn
+
+    # ---- a-5: WaDi-like sensors (reference myasp-wadi.py:57-98, 132-139), float32 as the reference casts (:73, :90, :135)
+    rng = np.random.default_rng(2024)
+    N, F, W = 300, 8, 25
+    level = np.array([812.5, 231.0, 0.0, 1004.75, 47.2, 3.5, 655.0, 0.0])
+    spread = np.array([0.012, 0.08, 1.0, 0.03, 0.0, 0.5, 0.05, 25.0])     # sensor 4 never moves (zero variance)
+    x = level + spread * rng.standard_normal((N, F))
+    x[:, 5] = np.where(rng.random(N) < 0.5, 3.5, 4.5)                      # a two-level actuator
+    x[rng.choice(N, 6, replace=False), 0] += 3.0                           # excursions far beyond +-10 IQR: the clip acts
+    x[rng.choice(N, 4, replace=False), 7] -= 900.0
+    x = x.astype(np.float32)
+    sample_idx = np.sort(rng.choice(np.arange(W, N), 200, replace=False))
+    windows = np.array([x[i - W + 1:i + 1].flatten() for i in sample_idx], dtype="float32")
+    all_windows = np.array([x[i - W + 1:i + 1].flatten() for i in range(W - 1, N)], dtype="float32")
+    out = {"x": x, "sample_idx": sample_idx.astype(np.int64), "W": np.int64(W)}
+    # (1) as the reference runs it: fit and transform float32 windows
+    sc32 = RobustScaler().fit(windows)
+    out["center_fit32"], out["scale_fit32"] = sc32.center_, sc32.scale_
+    out["scaled_fit32"] = np.clip(sc32.transform(all_windows), -10.0, 10.0)
+    # (2) a scaler whose center_ is float64 with low-order bits a float32 cannot hold (fit on float64
+    #     copies: medians of an even count are means of two float32 values), applied to the float32 windows
+    sc64 = RobustScaler().fit(windows.astype(np.float64))
+    out["center_fit64"], out["scale_fit64"] = sc64.center_, sc64.scale_
+    out["scaled_fit64"] = np.clip(sc64.transform(all_windows), -10.0, 10.0)
+    assert out["scaled_fit32"].dtype == np.float32 and out["scaled_fit64"].dtype == np.float32
+    assert sc32.scale_.dtype == np.float64 and sc64.center_.dtype == np.float64
+    assert np.any(sc64.center_ != sc64.center_.astype(np.float32))
+    assert np.any(np.abs(out["scaled_fit32"]) == 10.0)
+    # the oracle must be bit-equal to sklearn
+    for tag, sc in (("fit32", sc32), ("fit64", sc64)):
+        cen, scl = orc.robust_scaler_fit(windows if tag == "fit32" else windows.astype(np.float64))
+        assert cen.dtype == sc.center_.dtype and np.array_equal(cen, sc.center_), tag
+        assert np.array_equal(scl, sc.scale_), tag
+        mine = orc.vae_windows_multivariate(x, W, sc.center_, sc.scale_, 10.0)
+        assert np.array_equal(mine.view(np.uint32), out["scaled_" + tag].view(np.uint32)), tag
+    out["sklearn_version"] = np.array(sklearn.__version__)
+    np.savez_compressed(os.path.join(HERE, "robust_scaler_wadi_like.npz"), **out)
+
+    # ---- a-1, SMD: the reference's env_smd.py on a synthetic machine (sensor file: 38 columns, column 0 used)
+    import env_smd as ref_env_smd  # noqa: E402  (the reference's env_smd.py)
+    n = 700
+    col0 = np.round(12.5 + 9718.75 * rng.random(n) ** 3, 6)                # wide range: float64 vs float32 scaling differ
+    others = np.round(rng.random((n, 37)), 6)
+    labels = (rng.random(n) < 0.05).astype(int)
+    with tempfile.TemporaryDirectory() as td:
+        sd, ld = os.path.join(td, "test"), os.path.join(td, "test_label")
+        os.makedirs(sd)
+        os.makedirs(ld)
+        with open(os.path.join(sd, "machine-9-9.txt"), "w") as f:
+            for i in range(n):
+                f.write(",".join([repr(float(col0[i]))] + [repr(float(v)) for v in others[i]]) + "\n")
+        with open(os.path.join(ld, "machine-9-9.txt"), "w") as f:
+            f.write("\n".join(str(int(v)) for v in labels) + "\n")
+        with redirect_stdout(io.StringIO()):
+            e = ref_env_smd.EnvTimeSeriesfromRepo(sd + "/", ld + "/")
+        ts = e.timeseries_repo[0]
+        value = ts["value"].values
+        assert value.dtype == np.float32 and len(value) == n
+        mine, _, _ = orc.minmax_f64_to_f32(col0)
+        assert np.array_equal(mine.view(np.uint32), value.view(np.uint32))
+        f32way, _, _ = orc.minmax_f32(col0.astype(np.float32))
+        assert not np.array_equal(f32way.view(np.uint32), value.view(np.uint32))   # the variants really differ
+        np.savez_compressed(os.path.join(HERE, "smd_synth_machine.npz"), raw_col0=col0, value=value,
+                            anomaly=ts["anomaly"].values.astype(np.uint8))
+    # SMD-trained weights of the same univariate shapes (reference exp/SMD_*/checkpoints: data, read with this
+    # repo's bundle reader) for the SMD scoring test
+    prefix = os.path.join(REF, "exp", SMD_RUN, "checkpoints", "model")
+    save_model_npz(os.path.join(HERE, "ckpt_smd.npz"), load_q_estimator(prefix, "qlearn"),
+                   vae_from_chain(load_vae_dense_chain(prefix)))
+    print("scaler / SMD fixtures written")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "scalers":
+        scaler_and_smd_fixtures()
+        return
+    scaler_and_smd_fixtures()
     # ---- A1: all 67 normalised series (reference env.py), lexicographic order
     e1, names1, series1, anom1 = load_repo("A1Benchmark")
     flat, off = pack(series1)

@@ -165,7 +165,8 @@ int main() {
         std::vector<int32_t> act(K);
         drl_score_opts o{};
         o.struct_size = sizeof o; o.vae_lag = 0; o.flag_mode = DRL_FLAG_BOTH; o.action_rule = DRL_ACTION_WADI;
-        o.vae_center = cen.data(); o.vae_scale = scl.data(); o.vae_clip = 10.0f;
+        std::vector<double> cen64(cen.begin(), cen.end()), scl64(scl.begin(), scl.end());   // the ABI takes sklearn's float64
+        o.vae_center = cen64.data(); o.vae_scale = scl64.data(); o.vae_clip = 10.0f;
         CHECK(drl_score_batch(ctx, x.data(), off.data(), (int)lens.size(), F, Wm, &o, err.data(), q.data(), act.data(), margin.data()));
         EXPECT(finite(err) && finite(q));
         for (int64_t i = 0; i < K; ++i) EXPECT(act[i] == (q[4 * i + 3] > q[4 * i] ? 1 : 0));

@@ -27,7 +27,7 @@ def test_opts_struct_layout_matches_header():
     from drlvae import _abi
     body = re.search(r"typedef struct drl_score_opts \{(.*?)\} drl_score_opts;", _header(), re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"(?:const\s+)?(int32_t|float)\s*(\*?)\s*(\w+)\s*;", body)
+    fields = re.findall(r"(?:const\s+)?(int32_t|float|double)\s*(\*?)\s*(\w+)\s*;", body)
     assert [f[2] for f in fields] == [n for n, _ in _abi.ScoreOpts._fields_]
     for (typ, star, name), (_, ctype) in zip(fields, _abi.ScoreOpts._fields_):
         want = C.c_void_p if star else {"int32_t": C.c_int32, "float": C.c_float}[typ]

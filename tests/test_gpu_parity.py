@@ -346,6 +346,66 @@ def test_multivariate_wadi_formulation(scorer, F, H, N):
     np.testing.assert_allclose(out["margin"], np.abs(out["q"][:, 1, 1] - out["q"][:, 0, 0]), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("tag", ["fit32", "fit64"])
+def test_robust_scaler_on_the_sklearn_fixture(scorer, tag):
+    """a-5 where it is hard: sensors at level 1e2..1e3 with IQR 1e-2..1e-1, a sensor that never moves,
+    excursions beyond the clip.  Expected scaled windows are sklearn's own RobustScaler output (committed
+    fixture); "fit64" is a scaler whose float64 center_ has low-order bits float32 cannot hold — truncating it
+    would move the scaled input by up to |c64 - c32|/scale_ ~ 1e-3.  The float64 parameters cross the C-ABI as
+    they are; the tolerance on the error is the path's 1e-5."""
+    from drlvae import compat
+    z = np.load(os.path.join(GOLDEN, "robust_scaler_wadi_like.npz"))
+    x, Wn = z["x"], int(z["W"])
+    N, F = x.shape
+    D = Wn * F
+    cen, scl, Xs = z["center_" + tag], z["scale_" + tag], z["scaled_" + tag]
+    rng = np.random.default_rng(77)
+    for dims in ([D, 128, 10, 128, D], [D, 64, 10, 64, D]):            # LDS-staged wide kernel / chain kernel
+        vae = synth_vae(rng, dims, 1)
+        scorer.set_vae(vae)
+        rec = orc.vae_forward(Xs, vae["kernels"], vae["biases"], vae["acts"], 1, 2, dtype=np.float64)
+        want = orc.recon_error(Xs, rec, np.float64)                     # row j = window ending at sample j+W-1
+        got = scorer.score(x, Wn, vae_lag=0, want=("err",), vae_center=cen, vae_scale=scl, vae_clip=10.0)["err"]
+        np.testing.assert_allclose(got, want[1:], rtol=RTOL)            # window k ends at sample k+W
+        # the explicit-batch entry point on the host-scaled windows (what the reference hands vae.predict,
+        # myasp-wadi.py:143-145) agrees with the fused path far inside the tolerance
+        _, e2 = scorer.vae_predict(Xs[1:], return_err=True)
+        np.testing.assert_allclose(got, e2, rtol=2e-6)
+        print(f"{tag} {dims[1]}: fused == vae.predict(host-scaled) bit for bit on "
+              f"{np.mean(got.view(np.uint32) == e2.view(np.uint32)) * 100:.1f} % of the windows")
+        # compat.penalty_array (the reference's module-level array, myasp-wadi.py:148-149)
+        pen = compat.penalty_array(x, Wn, compat.KerasVAE(vae, scorer), cen, scl, 10.0)
+        np.testing.assert_allclose(pen[Wn - 1:], want, rtol=RTOL)
+        assert np.all(pen[:Wn - 1] == 0)
+    if tag == "fit64":
+        # the test is a hard one: with the center truncated to float32 the oracle itself leaves the tolerance
+        Xt = orc.vae_windows_multivariate(x, Wn, cen.astype(np.float32), scl, 10.0)
+        rt = orc.recon_error(Xt, orc.vae_forward(Xt, vae["kernels"], vae["biases"], vae["acts"], 1, 2, dtype=np.float64),
+                             np.float64)
+        assert np.max(np.abs(rt - want) / want) > RTOL
+
+
+def test_smd_series_normalised_in_float64(scorer):
+    """a-1, SMD variant end to end: the raw column normalised as env_smd.py does (float64, then cast;
+    compat.minmax_normalise — bit-equal to the fixture made by the reference's env_smd.py), scored with the
+    SMD-trained univariate networks of the reference's exp/SMD_* checkpoint."""
+    from drlvae import compat
+    z = np.load(os.path.join(GOLDEN, "smd_synth_machine.npz"))
+    lstm, vae = load_model_npz("ckpt_smd.npz")
+    v = compat.minmax_normalise(z["raw_col0"], np.float64)
+    assert np.array_equal(v.view(np.uint32), z["value"].view(np.uint32))
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    out = scorer.score(v, W, flag_mode="quirk")
+    want = orc.score_series_univariate(z["value"], W, vae, lstm, "quirk", dtype=np.float64)
+    np.testing.assert_allclose(out["err"], want["err"], rtol=RTOL)
+    assert_q_close(out["q"], want["q"])
+    assert_actions(out["action"], want["q"], want["action"])
+    # the float32 variant (env.py's arithmetic, also what in_scale/in_offset do on the device) is a different series
+    v32 = compat.minmax_normalise(z["raw_col0"].astype(np.float32), np.float32)
+    assert not np.array_equal(v32.view(np.uint32), v.view(np.uint32))
+
+
 def test_multivariate_h128_large_call_matches_small_calls(scorer):
     """Multivariate H = 128 (xproj + register-stationary recurrence): a large call runs 64-window
     tiles on a persistent grid, a small one 32-window tiles; same bits, and the small one is

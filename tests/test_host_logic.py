@@ -40,6 +40,17 @@ def test_minmax_params_are_sklearns(a1):
     assert sc == 1.0 and of == -3.0
 
 
+def test_minmax_normalise_float64_variant_is_env_smds(a1):
+    """compat.minmax_normalise(dtype=float64) = the value column of the reference's env_smd.py (fixture made by
+    importing it: tests/golden/make_golden.py); dtype=float32 = env.py's."""
+    from drlvae.compat import minmax_normalise
+    z = np.load(os.path.join(GOLDEN, "smd_synth_machine.npz"))
+    got = minmax_normalise(z["raw_col0"], np.float64)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), z["value"].view(np.uint32))
+    for raw, want in zip(a1["raw3"], a1["series"][:3]):
+        assert np.array_equal(minmax_normalise(raw).view(np.uint32), want.view(np.uint32))
+
+
 def test_vae_from_dense_chain_layout(ckpt_a1):
     from drlvae.compat import vae_from_dense_chain
     _, vae = ckpt_a1

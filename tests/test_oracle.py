@@ -132,3 +132,34 @@ def test_soft_kat_a1_al10000(a1):
             npos_ref = round(tp_ref / want[0]) if want[0] else 0
             assert abs(npos - npos_ref) <= 2, (j, npos, npos_ref)
     assert exact >= 5
+
+
+def test_robust_scaler_is_bit_equal_to_sklearn_fixture():
+    """a-5: the oracle's RobustScaler fit / transform / clip against what sklearn's own RobustScaler produced
+    in the build container (tests/golden/make_golden.py, scaler_and_smd_fixtures) on float32 windows of
+    WaDi-like sensors: levels up to 1e3 with IQR 1e-2, a sensor that never moves, excursions beyond the clip."""
+    z = np.load(os.path.join(GOLDEN, "robust_scaler_wadi_like.npz"))
+    x, W, idx = z["x"], int(z["W"]), z["sample_idx"]
+    windows = np.array([x[i - W + 1:i + 1].flatten() for i in idx], dtype="float32")
+    for tag, fit_on in (("fit32", windows), ("fit64", windows.astype(np.float64))):
+        cen, scl = orc.robust_scaler_fit(fit_on)
+        assert cen.dtype == z["center_" + tag].dtype
+        assert np.array_equal(cen, z["center_" + tag]) and np.array_equal(scl, z["scale_" + tag]), tag
+        got = orc.vae_windows_multivariate(x, W, z["center_" + tag], z["scale_" + tag], 10.0)
+        want = z["scaled_" + tag]
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32)), tag
+    assert np.any(z["scale_fit32"] == 1.0)                      # the zero-variance sensor (_handle_zeros_in_scale)
+    # what the float64 center buys: truncating it to float32 first moves the scaled input by far more than 1e-5
+    c64, s64 = z["center_fit64"], z["scale_fit64"]
+    trunc = orc.vae_windows_multivariate(x, W, c64.astype(np.float32), s64, 10.0)
+    assert np.abs(trunc - z["scaled_fit64"]).max() > 1e-4
+
+
+def test_smd_float64_minmax_is_bit_equal_to_env_smd_fixture():
+    """a-1, SMD variant: scaled in float64, cast afterwards (reference env_smd.py:76-77, 97); the fixture is the
+    value column of the reference's own env_smd.EnvTimeSeriesfromRepo on a synthetic machine file."""
+    z = np.load(os.path.join(GOLDEN, "smd_synth_machine.npz"))
+    got, _, _ = orc.minmax_f64_to_f32(z["raw_col0"])
+    assert np.array_equal(got.view(np.uint32), z["value"].view(np.uint32))
+    f32way, _, _ = orc.minmax_f32(z["raw_col0"].astype(np.float32))
+    assert not np.array_equal(f32way.view(np.uint32), z["value"].view(np.uint32))
