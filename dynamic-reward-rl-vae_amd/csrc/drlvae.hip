@@ -14,10 +14,29 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
+// ---- scratch of the entry point that allocates nothing (drl_score_batch_dev_noalloc) -------------
+// Everything that entry point needs on the device beyond the caller's inputs and outputs lives here: the
+// per-series tables, the option tables and the per-sample input projections P of the xproj paths.
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the process
+// ends.  In host code the NAME is only a handle for hipGetSymbolAddress (drl_create, once per device, with
+// that device current); everywhere else the per-device pointer g_scratch_dev[device] is used.
+#define DRL_SCRATCH_BYTES (32u << 20)
+#define DRL_SCRATCH_SEG_BYTES (64u << 10)        // [0, 64 KiB): per-series tables
+#define DRL_SCRATCH_OPT_BYTES (192u << 10)       // [64 KiB, 256 KiB): MinMax / RobustScaler tables
+#define DRL_SCRATCH_P_OFFSET (DRL_SCRATCH_SEG_BYTES + DRL_SCRATCH_OPT_BYTES)   // [256 KiB, 32 MiB): projections P
+#define DRL_NOALLOC_MAX_SEG 1024
+#define DRL_NOALLOC_MAX_D 8192
+static __device__ __align__(256) unsigned char scratch[DRL_SCRATCH_BYTES];
+
 namespace {
+
+constexpr int MAX_DEVICES = 64;
+unsigned char* g_scratch_dev[MAX_DEVICES] = {};   // device address of `scratch` on each GPU (drl_create)
+std::mutex g_scratch_mu;
 
 thread_local std::string g_create_error = "";
 
@@ -98,6 +117,12 @@ struct drl_ctx {
     DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
     void* pinned = nullptr;     // pinned host staging for the segment tables
     size_t pinned_cap = 0;
+    // the entry point that allocates nothing: this GPU's scratch array, and a fixed pinned staging block
+    // (allocated at drl_create) through which its tables reach the array; na_ev marks the last copy out of it
+    unsigned char* scratch_dev = nullptr;
+    void* na_stage = nullptr;
+    hipEvent_t na_ev = nullptr;
+    bool na_stage_busy = false;
     // pinned, device-mapped host memory for the inputs and outputs of the per-step calls (vae.predict /
     // estimator.predict on one state): the kernel reads and writes it directly, so such a call is one
     // launch and one stream synchronisation, no copies
@@ -237,31 +262,10 @@ struct SegHost {
     const int* d_t16 = nullptr;
 };
 
-// Builds and uploads the per-series tables.  n_win[i] = windows of series i.
-int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, bool windows_are_rows,
-                   SegHost& out) {
+// The per-series tables of a call, written to `host` (five arrays of n_seg+1 entries); totals into `out`.
+int seg_fill(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, bool windows_are_rows, void* host, SegHost& out) {
     const size_t n1 = (size_t)n_seg + 1;
-    const size_t bytes = n1 * (2 * sizeof(long long) + 3 * sizeof(int));
-    std::vector<int64_t> key(seg_offsets, seg_offsets + n1);
-    key.push_back(W);
-    key.push_back(windows_are_rows ? 1 : 0);
-    if (key == c->seg_key && c->seg.p) {
-        out.K_total = c->seg_K; out.tiles32 = c->seg_t32; out.tiles64 = c->seg_t64; out.tiles16 = c->seg_t16;
-        out.d_samp = (const long long*)c->seg.p;
-        out.d_win = out.d_samp + n1;
-        out.d_t32 = (const int*)(out.d_win + n1);
-        out.d_t64 = out.d_t32 + n1;
-        out.d_t16 = out.d_t64 + n1;
-        return DRL_OK;
-    }
-    c->seg_key.clear();
-    int rc = ensure_pinned(c, bytes);
-    if (rc) return rc;
-    rc = ensure(c, c->seg, bytes);
-    if (rc) return rc;
-    // the previous call's async copy out of the pinned buffer must be done before it is rewritten
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    long long* samp = (long long*)c->pinned;
+    long long* samp = (long long*)host;
     long long* win = samp + n1;
     int* t32 = (int*)(win + n1);
     int* t64 = t32 + n1;
@@ -287,17 +291,47 @@ int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, boo
     t32[n_seg] = (int)a32;
     t64[n_seg] = (int)a64;
     t16[n_seg] = (int)a16;
-    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
     out.K_total = wacc;
     out.tiles32 = (int)a32;
     out.tiles64 = (int)a64;
     out.tiles16 = (int)a16;
-    out.d_samp = (const long long*)c->seg.p;
+    return DRL_OK;
+}
+size_t seg_bytes(int n_seg) { return ((size_t)n_seg + 1) * (2 * sizeof(long long) + 3 * sizeof(int)); }
+void seg_point(SegHost& out, const void* dev, int n_seg) {
+    const size_t n1 = (size_t)n_seg + 1;
+    out.d_samp = (const long long*)dev;
     out.d_win = out.d_samp + n1;
     out.d_t32 = (const int*)(out.d_win + n1);
     out.d_t64 = out.d_t32 + n1;
     out.d_t16 = out.d_t64 + n1;
-    c->seg_key = key; c->seg_K = wacc; c->seg_t32 = out.tiles32; c->seg_t64 = out.tiles64; c->seg_t16 = out.tiles16;
+}
+
+// Builds and uploads the per-series tables (growing buffers of the context; cached while the same
+// layout is scored again).
+int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, bool windows_are_rows,
+                   SegHost& out) {
+    const size_t n1 = (size_t)n_seg + 1;
+    const size_t bytes = seg_bytes(n_seg);
+    std::vector<int64_t> key(seg_offsets, seg_offsets + n1);
+    key.push_back(W);
+    key.push_back(windows_are_rows ? 1 : 0);
+    if (key == c->seg_key && c->seg.p) {
+        out.K_total = c->seg_K; out.tiles32 = c->seg_t32; out.tiles64 = c->seg_t64; out.tiles16 = c->seg_t16;
+        seg_point(out, c->seg.p, n_seg);
+        return DRL_OK;
+    }
+    c->seg_key.clear();
+    int rc = ensure_pinned(c, bytes);
+    if (rc) return rc;
+    rc = ensure(c, c->seg, bytes);
+    if (rc) return rc;
+    // the previous call's async copy out of the pinned buffer must be done before it is rewritten
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = seg_fill(c, seg_offsets, n_seg, W, windows_are_rows, c->pinned, out))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    seg_point(out, c->seg.p, n_seg);
+    c->seg_key = key; c->seg_K = out.K_total; c->seg_t32 = out.tiles32; c->seg_t64 = out.tiles64; c->seg_t16 = out.tiles16;
     return DRL_OK;
 }
 
@@ -399,6 +433,27 @@ int drl_create(int device_id, drl_ctx** out) {
         c->overlap_mode = 0;                    // degrade to one stream, never fail creation for it
         c->aux_stream = nullptr;
     }
+    // this GPU's copy of the scratch array (once per device, with the device current: hipSetDevice above),
+    // and the fixed pinned block its tables travel through — set-up allocations; the entry point makes none
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (device_id < MAX_DEVICES && !g_scratch_dev[device_id]) {
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) {
+                drl_destroy(c);
+                return fail(nullptr, DRL_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device_id, hipGetErrorString(e));
+            }
+            g_scratch_dev[device_id] = (unsigned char*)p;
+        }
+        c->scratch_dev = device_id < MAX_DEVICES ? g_scratch_dev[device_id] : nullptr;
+    }
+    if (hipHostMalloc(&c->na_stage, DRL_SCRATCH_P_OFFSET, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->na_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->na_stage) { (void)hipHostFree(c->na_stage); c->na_stage = nullptr; }
+        c->scratch_dev = nullptr;               // drl_score_batch_dev_noalloc reports DRL_ERR_STATE
+    }
     if (const char* e = getenv("DRLVAE_FORCE_GENERIC")) c->force_generic = atoi(e) != 0;
     if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
     if (const char* e = getenv("DRLVAE_REC2")) c->rec2_mode = atoi(e);
@@ -419,6 +474,8 @@ void drl_destroy(drl_ctx* c) {
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_io) (void)hipHostFree(c->pin_io);
+    if (c->na_stage) (void)hipHostFree(c->na_stage);
+    if (c->na_ev) (void)hipEventDestroy(c->na_ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -676,17 +733,14 @@ struct OptDev {
     int rsP = 0;
 };
 
-// Uploads the small host-side option arrays (per series / per flattened column).  They are gathered
-// into one block; when the block equals the one already on the device (the usual case: the same
-// scaler for every call) nothing is copied, otherwise the stream is drained first — an earlier
-// asynchronous call may still be reading the old block.
-int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d) {
+// The small host-side option arrays (per series / per flattened column) gathered into one block:
+// in_scale[S] | in_offset[S] | RobustScaler table [4][P].
+int opts_fill(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, std::vector<float>& h, size_t& S, size_t& P) {
     if (o->in_scale && !o->in_offset) return fail(c, DRL_ERR_ARG, "opts.in_scale given without in_offset");
     if (o->vae_center && !o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
-    if (!o->in_scale && !o->vae_center) return DRL_OK;
-    const size_t S = o->in_scale ? up16(n_seg) : 0;
-    const size_t P = o->vae_center ? up32(D) : 0;      // padded to a whole 32-feature tile (center 0, 1/scale 1):
-    std::vector<float> h(2 * S + 4 * P, 0.0f);          // vae_wide_kernel streams them per tile
+    S = o->in_scale ? up16(n_seg) : 0;
+    P = o->vae_center ? up32(D) : 0;      // padded to a whole 32-feature tile (center 0, 1/scale 1):
+    h.assign(2 * S + 4 * P, 0.0f);        // vae_wide_kernel streams them per tile
     if (S) {
         memcpy(h.data(), o->in_scale, n_seg * sizeof(float));
         memcpy(h.data() + S, o->in_offset, n_seg * sizeof(float));
@@ -708,18 +762,54 @@ int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d
         hc[2 * P + i] = i_hi;
         hc[3 * P + i] = (float)(inv - (double)i_hi);
     }
+    return DRL_OK;
+}
+void opts_point(OptDev& d, const float* base, size_t S, size_t P) {
+    if (S) { d.in_scale = base; d.in_offset = base + S; }
+    if (P) { d.rs = base + 2 * S; d.rsP = (int)P; }
+}
+
+// Uploads that block into the context's growing buffer.  When it equals the one already on the
+// device (the usual case: the same scaler for every call) nothing is copied, otherwise the stream is
+// drained first — an earlier asynchronous call may still be reading the old block.
+int upload_opts(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, OptDev& d) {
+    std::vector<float> h;
+    size_t S = 0, P = 0;
+    int rc = opts_fill(c, o, n_seg, D, h, S, P);
+    if (rc) return rc;
+    if (h.empty()) return DRL_OK;
     if (!(c->opt.p && c->opt_S == S && c->opt_P == P && c->opt_host.size() == h.size() &&
           memcmp(c->opt_host.data(), h.data(), h.size() * sizeof(float)) == 0)) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        int rc = ensure(c, c->opt, h.size() * sizeof(float));
-        if (rc) return rc;
+        if ((rc = ensure(c, c->opt, h.size() * sizeof(float)))) return rc;
         HIP_TRY(c, hipMemcpy(c->opt.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
         c->opt_host.swap(h);
         c->opt_S = S; c->opt_P = P;
     }
-    const float* base = (const float*)c->opt.p;
-    if (S) { d.in_scale = base; d.in_offset = base + S; }
-    if (P) { d.rs = base + 2 * S; d.rsP = (int)P; }
+    opts_point(d, (const float*)c->opt.p, S, P);
+    return DRL_OK;
+}
+
+// The same two tables for the entry point that allocates nothing: through the fixed pinned block
+// into this GPU's scratch array, on the stream.  The block is reused by the next such call, which
+// first waits for this copy (na_ev).
+int noalloc_tables(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, const drl_score_opts* o, int D,
+                   SegHost& sh, OptDev& od) {
+    if (c->na_stage_busy) { HIP_TRY(c, hipEventSynchronize(c->na_ev)); c->na_stage_busy = false; }
+    int rc = seg_fill(c, seg_offsets, n_seg, W, false, c->na_stage, sh);
+    if (rc) return rc;
+    std::vector<float> h;                               // host memory only
+    size_t S = 0, P = 0;
+    if ((rc = opts_fill(c, o, n_seg, D, h, S, P))) return rc;
+    const size_t ob = h.size() * sizeof(float);
+    if (seg_bytes(n_seg) > DRL_SCRATCH_SEG_BYTES || ob > DRL_SCRATCH_OPT_BYTES)
+        return fail(c, DRL_ERR_ARG, "drl_score_batch_dev_noalloc: tables exceed the scratch layout");   // unreachable within the stated limits
+    if (ob) memcpy((char*)c->na_stage + DRL_SCRATCH_SEG_BYTES, h.data(), ob);
+    HIP_TRY(c, hipMemcpyAsync(c->scratch_dev, c->na_stage, DRL_SCRATCH_SEG_BYTES + ob, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->na_ev, c->stream));
+    c->na_stage_busy = true;
+    seg_point(sh, c->scratch_dev, n_seg);
+    opts_point(od, (const float*)(c->scratch_dev + DRL_SCRATCH_SEG_BYTES), S, P);
     return DRL_OK;
 }
 
@@ -740,7 +830,9 @@ int check_opts(drl_ctx* c, const drl_score_opts* o, int F) {
 // Device-pointer core shared by both entry points.
 int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, int n_seg, int F, int W,
                const drl_score_opts* o, const float* d_flags, const float* d_eps,
-               float* d_err, float* d_q, int32_t* d_action, float* d_margin, long long* K_out) {
+               float* d_err, float* d_q, int32_t* d_action, float* d_margin, long long* K_out, bool noalloc = false) {
+    // noalloc (drl_score_batch_dev_noalloc): tables and projections live in this GPU's scratch array,
+    // nothing is allocated, no profiling events are created
     const bool want_vae = d_err != nullptr;
     const bool want_q = d_q != nullptr || d_action != nullptr || d_margin != nullptr;
     if (want_vae) {
@@ -760,13 +852,35 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         if (!d_q) return fail(c, DRL_ERR_ARG, "action/margin need the q output buffer");
     }
     SegHost sh;
-    int rc = build_segments(c, seg_offsets, n_seg, W, false, sh);
-    if (rc) return rc;
-    if (K_out) *K_out = sh.K_total;
-    if (sh.K_total == 0) return DRL_OK;
     OptDev od;
-    rc = upload_opts(c, o, n_seg, W * F, od);
-    if (rc) return rc;
+    int rc;
+    if (noalloc) {
+        if ((rc = noalloc_tables(c, seg_offsets, n_seg, W, o, W * F, sh, od))) return rc;
+        if (K_out) *K_out = sh.K_total;
+        if (sh.K_total == 0) return DRL_OK;
+    } else {
+        if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
+        if (K_out) *K_out = sh.K_total;
+        if (sh.K_total == 0) return DRL_OK;
+        if ((rc = upload_opts(c, o, n_seg, W * F, od))) return rc;
+    }
+    // per-sample input projections of the xproj paths: the context's growing buffer, or the scratch array
+    auto projections = [&](size_t bytes, float** P) -> int {
+        if (noalloc) {
+            if (bytes > DRL_SCRATCH_BYTES - DRL_SCRATCH_P_OFFSET)
+                return fail(c, DRL_ERR_ARG, "drl_score_batch_dev_noalloc: %lld samples need %zu bytes of projections, "
+                            "the scratch array holds %u (limit: %u samples at hidden <= 64, %u above)",
+                            (long long)seg_offsets[n_seg], bytes, DRL_SCRATCH_BYTES - DRL_SCRATCH_P_OFFSET,
+                            (DRL_SCRATCH_BYTES - DRL_SCRATCH_P_OFFSET) / 1024, (DRL_SCRATCH_BYTES - DRL_SCRATCH_P_OFFSET) / 2048);
+            *P = (float*)(c->scratch_dev + DRL_SCRATCH_P_OFFSET);
+            return DRL_OK;
+        }
+        int r = ensure(c, c->pbuf, bytes);
+        if (r) return r;
+        *P = (float*)c->pbuf.p;
+        return DRL_OK;
+    };
+    const bool prof = c->prof.on && !noalloc;
 
     SegTab seg;
     seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t32;
@@ -785,7 +899,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         const bool wide = W * F > 128 && !d_eps && wide_lds <= 160 * 1024 &&
                           c->vae.dout[0] > 96 && c->vae.dout[0] <= 128 &&
                           c->vae.din[c->vae.n_path - 1] > 96 && c->vae.din[c->vae.n_path - 1] <= 128;
-        prof_begin(c, 1, vst);
+        if (prof) prof_begin(c, 1, vst);
         if (wide) {
             if (wide_lds > c->wide_lds_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide_kernel<true>),
@@ -802,7 +916,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             int rcl = launch_vae_chain(c, a, sh.tiles32, vst);
             if (rcl) return rcl;
         }
-        prof_end(c, vst);
+        if (prof) prof_end(c, vst);
         HIP_TRY(c, hipGetLastError());
         return DRL_OK;
     };
@@ -831,7 +945,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         // hidden widths 65..128 are packed zero-padded to 16 gate tiles x 64 k-steps (padded units stay at h = 0)
         const bool fast = c->lstm.I == 2 && c->lstm.NT == 16 && F == 1 && W >= 2 && W + 65 <= H128_SV;
         c->last_tile = 0;
-        prof_begin(c, 0, c->stream);
+        if (prof) prof_begin(c, 0, c->stream);
         if (fast && c->lstm_math == 1 && c->lstm.has_split) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             LstmF16Args fa;
@@ -866,10 +980,11 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             // recurrence from the projections
             const long long n_samples = seg_offsets[n_seg];
             const size_t pbytes = (size_t)n_samples * 16 * 32 * sizeof(float);
-            if ((rc = ensure(c, c->pbuf, pbytes))) return rc;
+            float* Pbuf = nullptr;
+            if ((rc = projections(pbytes, &Pbuf))) return rc;
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
-            xa.P = (float*)c->pbuf.p; xa.nt_total = 16;
+            xa.P = Pbuf; xa.nt_total = 16;
             xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128), 2), dim3(256), 0, c->stream, xa);
             RecArgs ra;
@@ -891,7 +1006,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             // H <= 64: project every sample once, then run the recurrences from the projections
             const long long n_samples = seg_offsets[n_seg];
             const size_t pbytes = (size_t)n_samples * 8 * 32 * sizeof(float);
-            if ((rc = ensure(c, c->pbuf, pbytes))) return rc;
+            float* Pbuf = nullptr;
+            if ((rc = projections(pbytes, &Pbuf))) return rc;
             const size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);   // U + the flag row
             if (!c->rec_attr_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
@@ -904,7 +1020,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             }
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
-            xa.P = (float*)c->pbuf.p; xa.nt_total = 8;
+            xa.P = Pbuf; xa.nt_total = 8;
             xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
             RecArgs ra;
@@ -945,7 +1061,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
             c->last_variant = "generic";
         }
-        prof_end(c, c->stream);
+        if (prof) prof_end(c, c->stream);
         HIP_TRY(c, hipGetLastError());
         if (overlap) {
             // the LSTM grid is already queued (it is the long one and takes the CUs first)
@@ -983,6 +1099,24 @@ int drl_score_batch_dev(drl_ctx* c, const float* series, const int64_t* seg_offs
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     return score_impl(c, series, seg_offsets, n_seg, F, W, o, o->flags, o->eps, recon_err, q, action, margin, nullptr);
+}
+
+int drl_score_batch_dev_noalloc(drl_ctx* c, const float* series, const int64_t* seg_offsets, int n_seg,
+                                int F, int W, const drl_score_opts* o,
+                                float* recon_err, float* q, int32_t* action, float* margin) {
+    if (!c) return DRL_ERR_ARG;
+    if (!series || !seg_offsets || n_seg < 1 || F < 1 || W < 1)
+        return fail(c, DRL_ERR_ARG, "drl_score_batch_dev_noalloc: bad series/seg_offsets/n_seg/F/W");
+    int rc = check_opts(c, o, F);
+    if (rc) return rc;
+    if (!c->scratch_dev || !c->na_stage || !c->na_ev)
+        return fail(c, DRL_ERR_STATE, "drl_score_batch_dev_noalloc: the scratch array was not set up at drl_create");
+    if (n_seg > DRL_NOALLOC_MAX_SEG)
+        return fail(c, DRL_ERR_ARG, "drl_score_batch_dev_noalloc: %d series, the limit is %d", n_seg, DRL_NOALLOC_MAX_SEG);
+    if ((long long)W * F > DRL_NOALLOC_MAX_D)
+        return fail(c, DRL_ERR_ARG, "drl_score_batch_dev_noalloc: window of %lld values, the limit is %d", (long long)W * F, DRL_NOALLOC_MAX_D);
+    HIP_TRY(c, hipSetDevice(c->device));
+    return score_impl(c, series, seg_offsets, n_seg, F, W, o, o->flags, o->eps, recon_err, q, action, margin, nullptr, true);
 }
 
 int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets, int n_seg,

@@ -16,7 +16,7 @@ COMM_ID_BYTES = 128
 # every symbol include/drlvae.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
-    "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_series",
+    "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_batch_dev_noalloc", "drl_score_series",
     "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
     "drl_last_lstm_variant", "drl_last_lstm_tile", "drl_last_call_overlapped",
     "drl_comm_unique_id", "drl_comm_init", "drl_allgather_scores", "drl_comm_destroy",
@@ -96,6 +96,7 @@ def load():
     score_args = [vp, vp, _i64p, C.c_int, C.c_int, C.c_int, C.POINTER(ScoreOpts), vp, vp, vp, vp]
     lib.drl_score_batch.argtypes = score_args
     lib.drl_score_batch_dev.argtypes = score_args
+    lib.drl_score_batch_dev_noalloc.argtypes = score_args
     lib.drl_score_series.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.POINTER(ScoreOpts), vp, vp, vp, vp]
     lib.drl_vae_predict.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
     lib.drl_q_predict.argtypes = [vp, vp, C.c_int64, C.c_int, vp]

@@ -184,10 +184,11 @@ class WindowScorer:
 
     # ------------------------------------------------------------------ fused path, device buffers
     def score_dev(self, series, W: int, offsets, out: Dict, *, vae_lag: int = 1, flag_mode="zeros",
-                  action_rule="argmax", **opt):
+                  action_rule="argmax", noalloc: bool = False, **opt):
         """Device-resident variant: ``series`` and the tensors in ``out`` ("err", "q", "action",
         "margin"; any subset) are torch tensors on this scorer's GPU.  Asynchronous on the
-        scorer's stream (see set_stream)."""
+        scorer's stream (see set_stream).  ``noalloc=True`` takes the entry point that allocates
+        nothing (drl_score_batch_dev_noalloc: bounded sizes, see include/drlvae.h)."""
         if series.dtype.__str__() != "torch.float32" or not series.is_contiguous():
             raise ValueError("series must be a contiguous float32 tensor")
         F = 1 if series.dim() == 1 else series.shape[1]
@@ -199,10 +200,10 @@ class WindowScorer:
             t = out.get(name)
             return None if t is None else int(t.data_ptr())
 
-        rc = self._lib.drl_score_batch_dev(self._h, int(series.data_ptr()),
-                                           off.ctypes.data_as(C.POINTER(C.c_int64)), len(off) - 1, F, int(W),
-                                           C.byref(o), dp("err"), dp("q"), dp("action"), dp("margin"))
-        self._check(rc, "drl_score_batch_dev")
+        fn = self._lib.drl_score_batch_dev_noalloc if noalloc else self._lib.drl_score_batch_dev
+        rc = fn(self._h, int(series.data_ptr()), off.ctypes.data_as(C.POINTER(C.c_int64)), len(off) - 1, F, int(W),
+                C.byref(o), dp("err"), dp("q"), dp("action"), dp("margin"))
+        self._check(rc, "drl_score_batch_dev_noalloc" if noalloc else "drl_score_batch_dev")
 
     # ------------------------------------------------------------------ call-surface compatibility
     def vae_predict(self, x, eps=None, return_err: bool = False):

@@ -152,6 +152,21 @@ int drl_score_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offset
 int drl_score_batch_dev(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg,
                         int F, int W, const drl_score_opts* opts,
                         float* recon_err, float* q, int32_t* action, float* margin);
+/* drl_score_batch_dev for callers that cannot allocate — code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
+ * same kernels and bit-identical results, but everything the call needs on the device beyond the
+ * caller's buffers (per-series tables, option tables, the per-sample input projections of the
+ * multivariate LSTM paths) lives in a file-scope array of 32 MiB that each GPU the library runs on
+ * holds until the process ends; the call makes no hipMalloc / hipFree / hipHostMalloc and creates no
+ * events (drl_profile_* does not see it).  Limits, rejected with DRL_ERR_ARG and a message:
+ *   n_seg <= 1024;  W*F <= 8192;  total samples <= 32,512 when the LSTM is a projection path with
+ *   hidden <= 64 (any F > 1, e.g. the WaDi / SMD QNet), <= 16,256 with hidden 65..128; the
+ *   univariate H <= 128 network (in_dim 2, F = 1) keeps no projections and has no sample limit.
+ * Every context on a GPU shares that GPU's array, which keeps the last call's contents: calls that
+ * overlap in time on one GPU (two contexts, or one context on two streams) race — serialise them. */
+int drl_score_batch_dev_noalloc(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg,
+                                int F, int W, const drl_score_opts* opts,
+                                float* recon_err, float* q, int32_t* action, float* margin);
 /* One series: drl_score_batch with n_seg = 1. */
 int drl_score_series(drl_ctx* ctx, const float* series, int64_t N, int F, int W,
                      const drl_score_opts* opts,

@@ -1,0 +1,102 @@
+"""The entry point that allocates nothing (drl_score_batch_dev_noalloc, include/drlvae.h): called through
+the C-ABI and checked against drl_score_batch_dev — same kernels, so bit for bit — on two calls in a row,
+the second with a smaller input; both the projection paths (whose per-sample projections live in the
+library's file-scope scratch array) and the univariate path; and its size limits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W = 25
+
+
+def _nets(rng, F, H):
+    from test_gpu_parity import synth_lstm, synth_vae
+    D = W * F
+    vae = synth_vae(rng, [D, 128, 10, 128, D] if F > 1 else [D, 64, 64, 64, 10, 64, D], 1 if F > 1 else 3)
+    return vae, synth_lstm(rng, F + 1, H)
+
+
+def _both_ways(sc, x, offsets, kw):
+    import torch
+    dev = torch.device("cuda", sc.device)
+    series = torch.from_numpy(x).to(dev)
+    K = int(np.maximum(np.diff(offsets) - W, 0).sum())
+    S = 2 if kw.get("flag_mode") == "both" else 1
+    res = []
+    for noalloc in (False, True):
+        out = {"err": torch.full((K,), -1.0, dtype=torch.float32, device=dev),
+               "q": torch.full((K, S, 2), -1.0, dtype=torch.float32, device=dev),
+               "action": torch.full((K,), -1, dtype=torch.int32, device=dev),
+               "margin": torch.full((K,), -1.0, dtype=torch.float32, device=dev)}
+        torch.cuda.synchronize()
+        sc.score_dev(series if x.shape[1] > 1 else series.reshape(-1), W, offsets, out, noalloc=noalloc, **kw)
+        sc.synchronize()
+        res.append({k: v.cpu().numpy() for k, v in out.items()})
+    return res
+
+
+@pytest.mark.parametrize("F,H", [(38, 64), (12, 128), (1, 128)])
+def test_noalloc_entry_point_matches_the_allocating_one(F, H):
+    from drlvae.scorer import WindowScorer
+    from oracle import ref_path as orc
+    rng = np.random.default_rng(1000 * F + H)
+    vae, lstm = _nets(rng, F, H)
+    sc = WindowScorer(0)
+    try:
+        sc.set_vae(vae)
+        sc.set_lstm(lstm)
+        D = W * F
+        if F > 1:
+            kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=rng.uniform(0.3, 0.7, D),
+                      vae_scale=rng.uniform(0.2, 0.6, D), vae_clip=10.0)
+        else:
+            kw = dict(vae_lag=1, flag_mode="quirk", action_rule="argmax", in_scale=None, in_offset=None)
+        # two calls in a row on the same scratch array, the second smaller (ragged: three series, one too short)
+        first = None
+        for lens in ([2600, 10, 1400], [700, 333]):
+            x = rng.random((sum(lens), F), dtype=np.float32)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            ref, got = _both_ways(sc, x, off, kw)
+            for k in ref:
+                assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), (lens, k)
+            assert np.all(got["err"] >= 0) and np.all(got["action"] >= 0)      # every output written
+            if first is None:
+                first = (x, off, got)
+        # and the first call against the oracle, to the path's tolerance (the reference check of section 3)
+        x, off, got = first
+        s0 = x[:off[1]]
+        if F > 1:
+            want = orc.score_series_multivariate(s0[:300], W, vae, lstm, kw["vae_center"], kw["vae_scale"], 10.0,
+                                                 dtype=np.float64)
+        else:
+            want = orc.score_series_univariate(s0[:300, 0], W, vae, lstm, "quirk", dtype=np.float64)
+        n = 300 - W
+        np.testing.assert_allclose(got["err"][:n], want["err"], rtol=1e-5)
+        qg, qw = got["q"][:n].reshape(n, -1).astype(np.float64), np.asarray(want["q"], np.float64).reshape(n, -1)
+        assert (np.abs(qg - qw).max(axis=1) / np.abs(qw).max(axis=1)).max() <= 1e-5
+    finally:
+        sc.close()
+
+
+def test_noalloc_entry_point_rejects_sizes_beyond_its_scratch():
+    import torch
+    from drlvae.scorer import WindowScorer
+    rng = np.random.default_rng(3)
+    F, H = 38, 64
+    vae, lstm = _nets(rng, F, H)
+    sc = WindowScorer(0)
+    try:
+        sc.set_lstm(lstm)
+        dev = torch.device("cuda", 0)
+        n = 32_513                                      # one sample more than the projections have room for
+        series = torch.zeros((n, F), dtype=torch.float32, device=dev)
+        out = {"q": torch.empty((n - W, 2, 2), dtype=torch.float32, device=dev)}
+        with pytest.raises(RuntimeError, match="scratch array holds"):
+            sc.score_dev(series, W, np.array([0, n], np.int64), out, flag_mode="both", noalloc=True)
+        sc.score_dev(series[:32_512], W, np.array([0, 32_512], np.int64), out, flag_mode="both", noalloc=True)
+        sc.synchronize()
+        with pytest.raises(RuntimeError, match="limit is 1024"):
+            sc.score_dev(series, W, np.arange(1026, dtype=np.int64) * 30, out, flag_mode="both", noalloc=True)
+    finally:
+        sc.close()
