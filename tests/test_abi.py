@@ -55,3 +55,52 @@ def test_header_is_plain_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{inc}", str(src), "-o", str(exe),
                     "-Wl,--unresolved-symbols=ignore-all"], check=True)
     assert subprocess.run([str(exe)]).returncode == 0          # struct layout = what _abi.ScoreOpts declares
+
+
+def _integration_snippet():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. C level"):text.index("## 3. Entry point")]
+    return re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+
+
+def test_integration_md_ctypes_example_declares_what_it_calls():
+    """INTEGRATION.md section 2 is executable: its declarations run here (no GPU needed) and every entry point
+    it calls has argtypes (a bare Python int would be passed as a 32-bit int and truncate a pointer)."""
+    from drlvae import _abi
+    src = _integration_snippet()
+    ns = {"LIB_PATH": _abi.LIB_PATH}
+    exec(compile(src, "INTEGRATION.md#2", "exec"), ns)
+    lib = ns["lib"]
+    called = set(re.findall(r"lib\.(drl_[a-z_]+)\(", src))
+    assert {"drl_create", "drl_set_vae", "drl_set_lstm", "drl_score_series", "drl_destroy", "drl_last_error"} <= called
+    for name in called:
+        assert getattr(lib, name).argtypes is not None, name
+    assert lib.drl_last_error.restype is C.c_char_p
+    assert C.sizeof(ns["ScoreOpts"]) == C.sizeof(_abi.ScoreOpts)
+    for (n1, t1), (n2, t2) in zip(ns["ScoreOpts"]._fields_, _abi.ScoreOpts._fields_):
+        assert n1 == n2 and t1 is t2
+
+
+@pytest.mark.gpu
+def test_integration_md_ctypes_example_runs(a1, ckpt_a1):
+    import numpy as np
+    import torch  # noqa: F401  a process that also uses torch imports it BEFORE the library (INTEGRATION.md section 2)
+    from drlvae import _abi
+    from drlvae.scorer import WindowScorer
+    ns = {"LIB_PATH": _abi.LIB_PATH}
+    exec(compile(_integration_snippet(), "INTEGRATION.md#2", "exec"), ns)
+    lstm, vae = ckpt_a1
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    v = f(a1["series"][0])
+    err, q, act, margin = ns["run"](v, [f(k) for k in vae["kernels"]], [f(b) for b in vae["biases"]], vae["acts"],
+                                    vae["mu_layer"], vae["logvar_layer"], f(lstm["kernel"]), f(lstm["bias"]),
+                                    f(lstm["w_out"]), f(lstm["b_out"]))
+    sc = WindowScorer(0)
+    try:
+        sc.set_vae(vae)
+        sc.set_lstm(lstm)
+        want = sc.score(v, 25, flag_mode="quirk")
+    finally:
+        sc.close()
+    for got, key in ((err, "err"), (q, "q"), (act, "action"), (margin, "margin")):
+        assert np.array_equal(got.view(np.uint32), want[key].view(np.uint32)), key
