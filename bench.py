@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
 """Throughput of the window-scoring path (VAE reward + LSTM-DQN Q / action / margin per window).
 
-One "step" = one pass of the hot path over one batch of synthetic series resident in HBM
-(drl_score_batch_dev).  With N > 1 ranks (torchrun, one process per GPU) every rank scores its own
-batch of the same shape (weak scaling, windows are independent) and the per-window scores are
-all-gathered over RCCL, the only collective of the path.
+One "step" = one pass of the hot path over one batch of series resident in HBM
+(drl_score_batch_dev).  Workloads:
+  N = 1 default        C2: the 67 Yahoo A1 series (committed fixture, normalised by the reference's env.py)
+                       with the reference's trained checkpoint weights — BASELINE.json configs[1];
+  N > 1 default        C5: a synthetic univariate stream, W = 50, weak-scaled (every rank its own stream of
+                       --windows windows, default 4e6 per GPU per step; north_star: 1.25e8);
+  --workload c4 --shard   one 172,801-sample WaDi-shaped stream strong-scaled over the ranks
+                       (drlvae.dist.shard_stream: contiguous window ranges with a W-1 sample halo).
+With N > 1 the per-window scores are all-gathered over RCCL (one packed block per rank per step,
+drlvae.dist.ScorePack), the only collective of the path.
 
-Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+`python bench.py --gpus N` from a bare shell starts the N ranks itself (a child
+`python -m torch.distributed.run`, before anything touches the GPU); under a launcher (WORLD_SIZE set)
+it is one rank.  Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,23 +61,37 @@ def make_lstm(rng, I, H, A=2):
             "w_out": glorot(rng, H, A), "b_out": np.zeros(A, np.float32), "forget_bias": 1.0}
 
 
-def a1_lengths():
+def a1_fixture():
+    """The 67 Yahoo A1 series as the reference's env.py normalises them, and the reference's trained
+    checkpoint (tests/golden/make_golden.py wrote both; they travel with the repository)."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "a1_series.npz"))
-    return np.diff(z["offsets"]).astype(np.int64)
+    w = np.load(os.path.join(ROOT, "tests", "golden", "ckpt_a1.npz"))
+    lstm = {k[5:]: w[k] for k in w.files if k.startswith("lstm_")}
+    lstm["forget_bias"] = 1.0
+    n = len(w["vae_acts"])
+    vae = {"kernels": [w[f"vae_k{i}"] for i in range(n)], "biases": [w[f"vae_b{i}"] for i in range(n)],
+           "acts": [int(a) for a in w["vae_acts"]], "mu_layer": int(w["vae_mu_layer"]),
+           "logvar_layer": int(w["vae_logvar_layer"]), "logvar_clip": float(w["vae_logvar_clip"])}
+    return z["values"].astype(np.float32), z["offsets"].astype(np.int64), vae, lstm
 
 
-def workload(name, rank, windows, hidden=0):
-    """Shapes of SURVEY.md §8(d).  Returns dict(series [N,F] float32, offsets, W, F, vae, lstm, opts)."""
+def workload(name, rank, windows, hidden=0, shard=None):
+    """Shapes of SURVEY.md §8(d).  Returns dict(series [N,F] float32, offsets, W, F, vae, lstm, opts).
+    shard = (rank, world): strong scaling, this rank's halo'd slice of the one stream (c4)."""
     rng_w = np.random.default_rng(1234)
+    data = "synthetic"
+    lstm = None
     if name in ("c1", "c2"):
         W, F, H = 25, 1, 128
-        lens = a1_lengths() if name == "c2" else a1_lengths()[:1]
-        rng = np.random.default_rng(100 + rank)
-        series = rng.random((int(lens.sum()), 1), dtype=np.float32)
-        vae = make_vae(rng_w, [25, 64, 64, 64, 10, 64, 25], 3)
-        desc = ("C2: 67 synthetic series with the Yahoo A1 lengths (93,191 windows), W=25, univariate, "
+        values, off, vae, lstm = a1_fixture()
+        n_ser = 67 if name == "c2" else 1
+        lens = np.diff(off)[:n_ser]
+        series = values[:off[n_ser], None]
+        data = ("real: Yahoo A1 series normalised by the reference's env.py + the reference's trained checkpoint "
+                "(committed fixtures); every rank scores the same series")
+        desc = ("C2: all 67 Yahoo A1 series in one ragged batch (93,191 windows), W=25, univariate, "
                 "VAE 25-64-64-64-10-64-25 + LSTM I2/H128" if name == "c2" else
-                "C1: one synthetic series of real_1's length (1,395 windows), W=25")
+                "C1: Yahoo A1 real_1 (1,395 windows), W=25")
         kw = dict(vae_lag=1, flag_mode="quirk", action_rule="argmax")
     elif name == "c5":
         W, F, H = 50, 1, 128
@@ -82,7 +106,7 @@ def workload(name, rank, windows, hidden=0):
         W = 25
         F, n, seed = (38, 28479, 38) if name == "c3" else (123, int(windows) + W if windows else 172801, 123)
         H = hidden or 64                 # SURVEY 8d lists H=64 (WaDi QNet) and H=128 (the reference's default)
-        rng = np.random.default_rng(seed + rank)
+        rng = np.random.default_rng(seed + (0 if shard else rank))
         if name == "c3":
             series = rng.random((n, F), dtype=np.float32)
         else:
@@ -100,9 +124,18 @@ def workload(name, rank, windows, hidden=0):
                 f"LSTM I{F+1}/H{H}, two candidate states per window")
         kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=center, vae_scale=scale,
                   vae_clip=10.0)
+        if shard:
+            from drlvae.dist import shard_stream
+            r, world = shard
+            s_lo, s_hi, k_lo, k_hi = shard_stream(n, W, r, world, 0)
+            series = np.ascontiguousarray(series[s_lo:s_hi])
+            lens = np.array([s_hi - s_lo])
+            desc += (f"; ONE stream sharded over {world} GPUs (strong scaling): rank {r} scores windows "
+                     f"[{k_lo:,}, {k_hi:,}) from samples [{s_lo:,}, {s_hi:,}) (W-1 sample halo)")
     else:
         raise SystemExit(f"unknown workload {name}")
-    lstm = make_lstm(rng_w, F + 1, H)
+    if lstm is None:
+        lstm = make_lstm(rng_w, F + 1, H)
     if name == "c4":
         lstm["kernel"][:F] *= 0.01
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -111,14 +144,18 @@ def workload(name, rank, windows, hidden=0):
     vae_flops = 2 * sum(chain[i] * chain[i + 1] for i in range(len(chain) - 1))
     lstm_flops = S * (2 * W * (F + 1 + H) * 4 * H + 2 * H * 2)
     return dict(name=name, desc=desc, series=series, offsets=offsets, W=W, F=F, H=H, S=S, vae=vae, lstm=lstm,
-                kw=kw, vae_flops=vae_flops, lstm_flops=lstm_flops,
+                kw=kw, vae_flops=vae_flops, lstm_flops=lstm_flops, data=data,
                 K=int(np.maximum(lens - W, 0).sum()))
 
 
 def cpu_baseline(wl):
-    """The oracle (numpy fp32 restatement of the reference's path, batched per series) timed on
-    the host cores of this box on a bounded sample of the same workload."""
+    """The oracle (fp32 CPU restatement of the reference's path, batched per series) timed on the host
+    cores of this box on a bounded sample of the same workload: the numpy restatement (oracle/ref_path.py,
+    BLAS threads) is the headline leg, the torch-CPU one (oracle/ref_path_torch.py) rides beside it
+    (SURVEY.md 8d names both), and ~2 s of the reference's own batch-1 call pattern."""
     from oracle import ref_path as orc
+    from oracle import ref_path_torch as orct
+    import torch
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -126,26 +163,32 @@ def cpu_baseline(wl):
         cores = os.cpu_count()
     W, F = wl["W"], wl["F"]
     x, off = wl["series"], wl["offsets"]
-    budget = 12.0                       # seconds of CPU work (bounded sample of the same workload)
-    done = 0
-    passes = 0
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget:
-        for i in range(len(off) - 1):
-            s = x[off[i]:off[i + 1]]
-            if F == 1:
-                n = min(len(s), 20000 + W)
-                orc.score_series_univariate(s[:n, 0], W, wl["vae"], wl["lstm"],
-                                            "quirk" if wl["kw"]["flag_mode"] == "quirk" else "zeros")
-            else:
-                n = min(len(s), 600 + W)
-                orc.score_series_multivariate(s[:n], W, wl["vae"], wl["lstm"], wl["kw"]["vae_center"],
-                                              wl["kw"]["vae_scale"], 10.0)
-            done += max(0, n - W)
-            if time.perf_counter() - t0 > budget:
-                break
-        passes += 1
-    dt = time.perf_counter() - t0
+    uni_mode = "quirk" if wl["kw"]["flag_mode"] == "quirk" else "zeros"
+
+    def leg(score_uni, score_multi, budget):
+        done, passes, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            for i in range(len(off) - 1):
+                s = x[off[i]:off[i + 1]]
+                if F == 1:
+                    n = min(len(s), 20000 + W)
+                    score_uni(s[:n, 0])
+                else:
+                    n = min(len(s), 600 + W)
+                    score_multi(s[:n])
+                done += max(0, n - W)
+                if time.perf_counter() - t0 > budget:
+                    break
+            passes += 1
+        return done, passes, time.perf_counter() - t0
+
+    done, passes, dt = leg(lambda v: orc.score_series_univariate(v, W, wl["vae"], wl["lstm"], uni_mode),
+                           lambda m: orc.score_series_multivariate(m, W, wl["vae"], wl["lstm"], wl["kw"]["vae_center"],
+                                                                   wl["kw"]["vae_scale"], 10.0), 8.0)
+    tthreads = torch.get_num_threads()
+    tdone, tpasses, tdt = leg(lambda v: orct.score_series_univariate(v, W, wl["vae"], wl["lstm"], uni_mode),
+                              lambda m: orct.score_series_multivariate(m, W, wl["vae"], wl["lstm"], wl["kw"]["vae_center"],
+                                                                       wl["kw"]["vae_scale"], 10.0), 6.0)
     # the reference's own call pattern (one vae.predict + one estimator.predict per window, batch 1:
     # SURVEY.md 3.1), ~2 s of it, reported beside the batched figure
     b1 = None
@@ -164,6 +207,9 @@ def cpu_baseline(wl):
         b1 = {"value": n1 / (time.perf_counter() - t1), "unit": "windows/s",
               "sample": f"{n1} windows, one batch-1 VAE call + one batch-1 LSTM call each (the reference's call pattern)"}
     return {"value": done / dt, "unit": "windows/s", "cores": int(cores), "kind": "port", "call_pattern_batch1": b1,
+            "torch_cpu_fp32": {"value": tdone / tdt, "unit": "windows/s", "cores": int(tthreads),
+                               "sample": f"{tdone:,} windows ({tpasses} pass(es)) in {tdt:.1f} s; oracle/ref_path_torch.py, "
+                                         f"torch {torch.__version__} CPU, {tthreads} threads"},
             "sample": f"{done:,} windows ({passes} pass(es) over the head of the same workload) in {dt:.1f} s; "
                       f"oracle/ref_path.py = numpy fp32 restatement, whole-series batches through BLAS "
                       f"(not the reference's TF path, which cannot run here; its batch-1 call pattern is "
@@ -172,9 +218,10 @@ def cpu_baseline(wl):
 
 def pmc_traffic(name, variant):
     """HBM bytes per launch of the dominant kernel (the LSTM variant that ran) from the committed
-    rocprofv3 PMC summary of the same workload (profiles/rNN/<workload>_pmc_summary.json), or None."""
+    rocprofv3 PMC summary of the same workload (profiles/rNN/<workload>_pmc_summary.json, newest round),
+    or None."""
     kern = {"h128i2": "lstm_h128i2_kernel", "h128i2_f16x3": "lstm_h128i2_f16x3_kernel",
-            "xproj+rec": "lstm_rec_kernel", "xproj+h128": "lstm_h128p_kernel", "generic": "lstm_generic_kernel"}.get(variant, "lstm_")
+            "xproj+rec": "lstm_rec", "xproj+h128": "lstm_h128p_kernel", "generic": "lstm_generic_kernel"}.get(variant, "lstm_")
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{name}_pmc_summary.json"))):
@@ -183,12 +230,34 @@ def pmc_traffic(name, variant):
         return None
     try:
         d = json.load(open(best))
+        tot = 0.0
         for k, v in d["kernels"].items():
             if kern in k and "hbm_bytes_per_launch" in v:
-                return v["hbm_bytes_per_launch"]
+                tot += v["hbm_bytes_per_launch"]
+        return tot or None
     except Exception:
         return None
-    return None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a child torchrun.  This process has
+    touched no GPU (torch is not even imported yet) and never does; it passes the child's output through
+    and exits with its code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def main():
@@ -196,27 +265,38 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="default: c2 on one GPU, c5 (weak-scaled) on several")
+    ap.add_argument("--shard", action="store_true",
+                    help="strong scaling: ONE stream (c4) sharded over the ranks instead of one stream per rank")
     ap.add_argument("--windows", type=float, default=0, help="windows per GPU for c5 (default 4e6) / c4")
     ap.add_argument("--lstm-math", default="fp32", choices=["fp32", "f16x3"],
                     help="recurrent product of the univariate H=128 LSTM: exact fp32 MFMA or 3-term f16 split")
     ap.add_argument("--hidden", type=int, default=0, help="LSTM hidden width for c3/c4 (64 default, 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the f16x3 side measurement")
     ap.add_argument("--collective", default="torch", choices=["torch", "abi"],
                     help="the all-gather of the scores: torch.distributed (RCCL) or the library's own RCCL "
                          "entry point drl_allgather_scores on the scoring stream")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                            # does not return
+
     import torch
     import torch.distributed as dist
+    from drlvae.dist import ScorePack
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.workload is None:
+        args.workload = "c2" if world == 1 else "c5"
+    if args.shard and args.workload != "c4":
+        raise SystemExit("--shard is the strong-scaling form of --workload c4")
     # rehearsal of the N>1 path on a one-GPU box: DRLVAE_BENCH_REHEARSE=1 puts every rank on cuda:0 and
     # swaps RCCL (which refuses two ranks on one device) for gloo.  Never a measurement.
     rehearse = os.environ.get("DRLVAE_BENCH_REHEARSE") == "1"
@@ -235,7 +315,7 @@ def main():
 
     if args.workload == "c5" and not args.windows:
         args.windows = 4e6
-    wl = workload(args.workload, rank, args.windows, args.hidden)
+    wl = workload(args.workload, rank, args.windows, args.hidden, (rank, world) if args.shard else None)
     from drlvae.scorer import WindowScorer
     sc = WindowScorer(local)
     sc.set_vae(wl["vae"])
@@ -245,24 +325,29 @@ def main():
     sc.set_stream(stream.cuda_stream)
 
     K, S = wl["K"], wl["S"]
+    gather = world > 1 and not args.no_allgather
+    # windows per rank: equal under weak scaling, within one of each other when one stream is sharded
+    if world > 1:
+        ks = [None] * world
+        dist.all_gather_object(ks, K)
+    else:
+        ks = [K]
+    K_cap, K_total = max(ks), sum(ks)
     with torch.cuda.stream(stream):
         series = torch.from_numpy(wl["series"]).to(dev)
-        # one score record block per rank: [err K | q K*S*2 | action K (i32 bits) | margin K], 4-byte
-        # words, so that the whole result travels in ONE all-gather per step.  Two sets of buffers: the
-        # all-gather of step i runs (on RCCL's stream) under the kernels of step i+1.
-        words = K * (3 + 2 * S)
-        nbuf = 2 if world > 1 and not args.no_allgather else 1
-        packs = [torch.empty(words, dtype=torch.float32, device=dev) for _ in range(nbuf)]
-        outs = [{"err": p[:K], "q": p[K:K + 2 * S * K].view(K, S, 2),
-                 "action": p[K + 2 * S * K:2 * K + 2 * S * K].view(torch.int32), "margin": p[2 * K + 2 * S * K:]}
-                for p in packs]
-        gathered = None
-        if world > 1 and not args.no_allgather:
-            # rank r's block lands at words [r*words, (r+1)*words)
-            gathered = [torch.empty(world * words, dtype=torch.float32, device=cdev) for _ in range(nbuf)]
+        # one ScorePack per rank and step: [err | q | action | margin] as 4-byte words, so that the whole
+        # result travels in ONE all-gather.  Two sets of buffers: the all-gather of step i runs (on RCCL's
+        # stream) under the kernels of step i+1.
+        nbuf = 2 if gather else 1
+        packs = [ScorePack(K_cap, S, 2, dev) for _ in range(nbuf)]
+        outs = [p.views(K) for p in packs]
+        for o in outs:
+            if S == 1:
+                o["q"] = o["q"].view(K, 1, 2)
+        gathered = [torch.empty(world * packs[0].words, dtype=torch.float32, device=cdev) for _ in range(nbuf)] if gather else None
     stream.synchronize()
 
-    use_abi = gathered is not None and args.collective == "abi" and not rehearse
+    use_abi = gather and args.collective == "abi" and not rehearse
     if use_abi:
         ids = [sc.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -280,11 +365,13 @@ def main():
             pending[b] = None
         sc.score_dev(series, wl["W"], wl["offsets"], outs[b], **wl["kw"])
         if use_abi:
-            sc.allgather(packs[b], gathered[b])          # RCCL on the scoring stream, no torch in between
-        elif gathered is not None:
+            sc.allgather(packs[b].buf, gathered[b])      # RCCL on the scoring stream, no torch in between
+        elif gather:
             with torch.cuda.stream(stream):
-                pending[b] = dist.all_gather_into_tensor(gathered[b], packs[b].cpu() if rehearse else packs[b],
-                                                         async_op=True)
+                if rehearse:
+                    pending[b] = dist.all_gather_into_tensor(gathered[b], packs[b].buf.cpu(), async_op=True)
+                else:
+                    pending[b] = packs[b].all_gather(gathered[b], async_op=True)
 
     def fence():
         with torch.cuda.stream(stream):
@@ -298,57 +385,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps, profile=True):
+        fence()
+        if profile:
+            sc.profile(True)
+            sc.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        res = (sc.profile_read(0), sc.profile_read(1)) if profile else None
+        if profile:
+            sc.profile(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, res
+
     for _ in range(args.warmup):
         step()
-    fence()
-    sc.profile(True)
-    sc.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    lstm_ms, lstm_n = sc.profile_read(0)
-    vae_ms, vae_n = sc.profile_read(1)
-    sc.profile(False)
+    dt, ((lstm_ms, lstm_n), (vae_ms, vae_n)) = timed(args.steps)
     variant = sc.lstm_variant  # of the headline run (the alt run below changes it)
     overlapped = sc.overlapped
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+
+    # the rate of ONE GPU on this same workload with the collective off (rank 0's own kernels, same steps):
+    # what a weak-scaling efficiency of this line should be read against (the N = 1 default is another workload)
+    single = None
+    if gather:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sc.score_dev(series, wl["W"], wl["offsets"], outs[0], **wl["kw"])
+        fence()
+        single = {"value": K * args.steps / (time.perf_counter() - t0), "unit": "windows/s",
+                  "what": "rank 0 alone on its share of this workload, collective off, same step count"}
 
     # the same workload once more with the other arithmetic of the H=128 recurrent product, reported
     # beside the headline (never as `value`): the 3-term compensated f16 split
     alt = None
-    if variant.startswith("h128i2") and args.lstm_math == "fp32":
+    if variant.startswith("h128i2") and args.lstm_math == "fp32" and not args.no_alt:
         sc.set_lstm_math("f16x3")
         for _ in range(max(1, args.warmup)):
             step()
-        fence()
-        sc.profile(True)
-        sc.profile_reset()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt2 = time.perf_counter() - t1
-        ms2, n2 = sc.profile_read(0)
-        sc.profile(False)
-        if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
+        dt2, ((ms2, n2), _) = timed(args.steps)
         alt = {"lstm_math": "f16x3 (h.U as h_hi.U_hi + h_hi.U_lo + h_lo.U_hi on the f16 matrix pipe, fp32 accumulate; "
                             "same 1e-5 parity tests as fp32, measured ~3e-7 from the fp64 oracle)",
-               "value": K * world * args.steps / dt2, "unit": "windows/s", "ms_per_step": dt2 / args.steps * 1e3,
+               "value": K_total * args.steps / dt2, "unit": "windows/s", "ms_per_step": dt2 / args.steps * 1e3,
                "lstm_kernel": sc.lstm_variant, "lstm_kernel_avg_ms": ms2 / max(n2, 1)}
         sc.set_lstm_math("fp32")
 
     if rank == 0:
-        total_windows = K * world * args.steps
+        total_windows = K_total * args.steps
         lstm_avg_s = lstm_ms / max(lstm_n, 1) / 1e3
-        achieved = wl["lstm_flops"] * K / lstm_avg_s / 1e12 if lstm_n else 0.0
+        Hh, Ff, Ww = wl["H"], wl["F"], wl["W"]
+        n_samples = int(wl["series"].shape[0])
+        algorithmic = wl["lstm_flops"] * K
+        # what the launch really executes: the xproj paths project each SAMPLE once, not each window's W rows
+        executed = (n_samples * 2 * Ff * 4 * Hh + K * S * (Ww * 2 * Hh * 4 * Hh + 2 * Hh * 2)
+                    if variant.startswith("xproj") else algorithmic)
+        achieved = executed / lstm_avg_s / 1e12 if lstm_n else 0.0
         res = {
             "metric": "windows scored/sec (VAE reward + LSTM Q)",
             "value": total_windows / dt,
@@ -358,14 +455,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.shard else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.lstm_math == "fp32" else "f16x3-split MFMA, f32 accumulate",
-            "data": "synthetic",
-            "config": {"workload": wl["desc"], "windows_per_gpu_per_step": K, "window": wl["W"],
-                       "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
+            "data": wl["data"],
+            "config": {"workload": wl["desc"], "windows_per_gpu_per_step": K, "windows_per_rank": ks,
+                       "windows_per_step_all_gpus": K_total, "ranks": world,
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "window": wl["W"], "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
-                       "collective": ("none" if gathered is None else "gloo all_gather (REHEARSAL, not a measurement)"
+                       "collective": ("none" if not gather else "gloo all_gather (REHEARSAL, not a measurement)"
                                       if rehearse else ("one rccl all_gather (drl_allgather_scores) of the packed err/q/action/margin block per step"
                                                        if use_abi else "one rccl all_gather of the packed err/q/action/margin block per step, overlapped with the next step's kernels")),
                        "lstm_kernel": variant,
@@ -376,23 +475,24 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": (4 * wl["F"] + 4 + 4 * 2 * S + 4) * K,
                          "avg_launch_ms": lstm_avg_s * 1e3, "launches": lstm_n,
-                         "flop_per_launch": wl["lstm_flops"] * K,
+                         "flop_per_launch": executed,
                          "vae_kernel_avg_ms": vae_ms / max(vae_n, 1)},
         }
         if variant.startswith("xproj"):
-            # `achieved` prices the path the way the reference runs it (every window re-projects its W input
-            # rows: SURVEY 8d's per-window figure).  These kernels project each SAMPLE once, so the flop they
-            # actually execute is smaller; for the record, the executed rate too:
-            Hh, Ff, Ww = wl["H"], wl["F"], wl["W"]
-            n_samples = int(wl["series"].shape[0])
-            executed = n_samples * 2 * Ff * 4 * Hh + K * S * (Ww * 2 * Hh * 4 * Hh + 2 * Hh * 2)
-            res["roofline"]["executed_flop_per_launch"] = executed
-            res["roofline"]["executed_frac"] = executed / lstm_avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS if lstm_n else 0.0
+            # `frac` prices the flop the launch executes.  The reference re-projects the W input rows of every
+            # window (SURVEY 8d's per-window figure); for the record, that algorithmic count over the same time:
+            res["roofline"]["algorithmic_flop_per_launch"] = algorithmic
+            res["roofline"]["algorithmic_frac"] = algorithmic / lstm_avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS if lstm_n else 0.0
+        if overlapped:
+            res["roofline"]["note"] = ("the VAE kernel runs on a second stream beside the LSTM kernels: avg_launch_ms is "
+                                       "the LSTM kernels' span while they share the CUs with it")
         tr = res["roofline"]["traffic"]
         if tr and lstm_avg_s > 0:
             # the other roofline, for the record: this path sits at a fraction of a percent of HBM
             res["roofline"]["hbm_achieved_GBps"] = tr / lstm_avg_s / 1e9
             res["roofline"]["hbm_frac_of_8TBps"] = tr / lstm_avg_s / 8e12
+        if single is not None:
+            res["single_gpu_same_workload"] = single
         if alt is not None:
             res["alt_arithmetic"] = alt
         if world == 1 and not args.no_cpu_baseline:

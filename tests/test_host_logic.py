@@ -83,6 +83,45 @@ def test_shard_plans():
     assert abs(loads[0] - loads[1]) <= max(lens)
 
 
+def test_score_pack_layout():
+    """The packed block every rank all-gathers: err | q | action (int32 bits) | margin, capacity-padded."""
+    import torch
+    from drlvae.dist import ScorePack
+    p = ScorePack(7, S=2, A=2)
+    assert p.words == 7 * (3 + 4) and p.buf.dtype == torch.float32
+    v = p.views(5)
+    assert v["err"].shape == (5,) and v["q"].shape == (5, 2, 2) and v["action"].dtype == torch.int32
+    v["err"][:] = 1.0
+    v["q"][:] = 2.0
+    v["action"][:] = torch.arange(5, dtype=torch.int32)
+    v["margin"][:] = 4.0
+    b = p.buf
+    assert b[:5].eq(1).all() and b[5:7].eq(0).all() and b[7:7 + 20].eq(2).all() and b[27:35].eq(0).all()
+    assert b[35:40].view(torch.int32).tolist() == [0, 1, 2, 3, 4] and b[42:47].eq(4).all()
+    # a gathered buffer of two ranks, the second with fewer windows
+    g = torch.cat([p.buf, torch.zeros_like(p.buf)])
+    assert p.rank_views(g, 0, 5)["action"].tolist() == [0, 1, 2, 3, 4]
+    assert p.rank_views(g, 1, 3)["q"].shape == (3, 2, 2)
+    assert ScorePack(4).views()["q"].shape == (4, 2)
+
+
+def test_bench_starts_its_own_ranks_from_a_bare_invocation():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks itself (a child torchrun)
+    and exit with their status.  There is no GPU here, so both ranks fail at device set-up: what is checked is
+    that two ranks ran and that their failure is the parent's exit code (never a silent success)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU tests run bench.py for real")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launch with" not in r.stderr + r.stdout
+    assert "local_rank: 0" in r.stderr or "rank      : 0" in r.stderr or "rank 0" in r.stderr.lower() or "[rank0]" in r.stderr \
+        or "ChildFailedError" in r.stderr, r.stderr[-2000:]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

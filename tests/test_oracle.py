@@ -163,3 +163,15 @@ def test_smd_float64_minmax_is_bit_equal_to_env_smd_fixture():
     assert np.array_equal(got.view(np.uint32), z["value"].view(np.uint32))
     f32way, _, _ = orc.minmax_f32(z["raw_col0"].astype(np.float32))
     assert not np.array_equal(f32way.view(np.uint32), z["value"].view(np.uint32))
+
+
+def test_torch_cpu_leg_agrees_with_the_numpy_oracle(a1, ckpt_a1):
+    """oracle/ref_path_torch.py (bench.py's second cpu_baseline leg) is the same restatement on torch-CPU."""
+    from oracle import ref_path_torch as orct
+    lstm, vae = ckpt_a1
+    v = a1["series"][0][:400]
+    a = orc.score_series_univariate(v, W, vae, lstm, "quirk")
+    b = orct.score_series_univariate(v, W, vae, lstm, "quirk")
+    np.testing.assert_allclose(b["err"], a["err"], rtol=2e-6)
+    np.testing.assert_allclose(b["q"], a["q"], rtol=1e-5)
+    assert np.array_equal(a["action"], b["action"])
