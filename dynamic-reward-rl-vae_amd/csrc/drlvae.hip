@@ -4,6 +4,7 @@
 #include "kernels.hip.h"
 #include "lstm_f16x3.hip.h"
 #include "lstm_w16.hip.h"
+#include "vae_wide16.hip.h"
 
 #include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
@@ -57,7 +58,9 @@ struct VaeHost {
     int latent = 0;
     int D = 0;                            // input width
     bool narrow = false;                  // every hidden width <= 64: vae_kernel<2>
-    size_t pack_floats = 0;               // size of the whole weight pack
+    size_t pack_floats = 0;               // size of the chain kernels' weight pack (what vae_kernel<.., true> copies to LDS)
+    bool wide16 = false;                  // wide windows with a 97..128-wide first/last hidden layer: vae_wide16_kernel
+    size_t w16_off[DRL_MAX_VAE_LAYERS], b16_off[DRL_MAX_VAE_LAYERS];   // its 16-row-tile layout, after the chain pack
 };
 
 struct LstmHost {
@@ -565,6 +568,20 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
     }
     v.lv_clip = std::isfinite(logvar_clip) ? logvar_clip : 0.0f;
     v.pack_floats = off;
+    // wide windows (vae_wide16_kernel): a second copy of the path's weights in 16-row-tile order
+    const int last = v.n_path - 1;
+    v.wide16 = v.D > 128 && v.dout[0] > 96 && v.dout[0] <= 128 && v.din[last] > 96 && v.din[last] <= 128;
+    for (int p = 1; p < last && v.wide16; ++p) v.wide16 = v.din[p] <= 128 && v.dout[p] <= 128;
+    if (v.wide16) {
+        const size_t nslab = (v.D + 31) / 32;
+        for (int p = 0; p < v.n_path; ++p) {
+            const size_t nin16 = (v.din[p] + 15) / 16, nout16 = (v.dout[p] + 15) / 16;
+            v.w16_off[p] = off;
+            off += (p == 0 || p == last) ? nslab * VW16_SLAB : nout16 * nin16 * 4 * 64;
+            v.b16_off[p] = off;
+            off += (p == last) ? nslab * 32 : up16(nout16 * 16);
+        }
+    }
     std::vector<float> pack(off, 0.0f);
     for (int p = 0; p < v.n_path; ++p) {
         const int l = path[p];
@@ -577,6 +594,56 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
     if (v.has_lv) {
         pack_dense(kernels[logvar_layer], in_dims[logvar_layer], v.latent, pack.data() + v.wlv_off, false, 1.0);
         pack_bias(biases[logvar_layer], v.latent, pack.data() + v.blv_off, 1.0);
+    }
+    if (v.wide16) {
+        // layouts: vae_wide16.hip.h (lane l: q = l >> 4 is the k index, l & 15 the output row of a 16-row tile)
+        const int D = v.D, nslab = (D + 31) / 32;
+        for (int p = 0; p < v.n_path; ++p) {
+            const float* K = kernels[path[p]];
+            const float* B = biases[path[p]];
+            const int din = v.din[p], dout = v.dout[p];
+            // v.act[last] was rewritten to 3 above when the output sigmoid is folded: same scale here
+            const double scale = (p == last && v.act[p] == 3) ? -1.4426950408889634 : 1.0;
+            float* w = pack.data() + v.w16_off[p];
+            float* b = pack.data() + v.b16_off[p];
+            auto at = [&](int in, int out) -> float {
+                return (in < din && out < dout) ? (float)(scale * K[(size_t)in * dout + out]) : 0.0f;
+            };
+            if (p == 0) {
+                for (int it = 0; it < nslab; ++it)
+                    for (int T = 0; T < 8; ++T)
+                        for (int kg = 0; kg < 2; ++kg)
+                            for (int l = 0; l < 64; ++l)
+                                for (int j = 0; j < 4; ++j)
+                                    w[(size_t)it * VW16_SLAB + (((T * 2 + kg) * 64 + l) * 4 + j)] =
+                                        at(it * 32 + 4 * (4 * kg + j) + (l >> 4), 16 * T + (l & 15));
+            } else if (p == last) {
+                for (int ot = 0; ot < nslab; ++ot)
+                    for (int T2 = 0; T2 < 2; ++T2)
+                        for (int Tin = 0; Tin < 8; ++Tin)
+                            for (int l = 0; l < 64; ++l)
+                                for (int r = 0; r < 4; ++r)
+                                    w[(size_t)ot * VW16_SLAB + (((T2 * 8 + Tin) * 64 + l) * 4 + r)] =
+                                        at(16 * Tin + 4 * (l >> 4) + r, ot * 32 + 16 * T2 + (l & 15));
+                for (int d = 0; d < nslab * 32; ++d) b[d] = d < dout ? (float)(scale * B[d]) : 0.0f;
+            } else {
+                const int nin16 = (din + 15) / 16, nout16 = (dout + 15) / 16;
+                for (int ot = 0; ot < nout16; ++ot)
+                    for (int Tin = 0; Tin < nin16; ++Tin)
+                        for (int r = 0; r < 4; ++r)
+                            for (int l = 0; l < 64; ++l)
+                                w[(((size_t)ot * nin16 + Tin) * 4 + r) * 64 + l] = at(16 * Tin + 4 * (l >> 4) + r, 16 * ot + (l & 15));
+            }
+            if (p != last) {
+                const int nout16 = (dout + 15) / 16;
+                for (int ot = 0; ot < nout16; ++ot)
+                    for (int qq = 0; qq < 4; ++qq)
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = 16 * ot + 4 * qq + r;
+                            b[(ot * 4 + qq) * 4 + r] = o < dout ? (float)(scale * B[o]) : 0.0f;
+                        }
+            }
+        }
     }
     int rc = ensure(c, c->vae_w, off * sizeof(float));
     if (rc) { c->vae.set = false; return rc; }      // the old pack may be gone: no stale weights
@@ -740,7 +807,7 @@ int opts_fill(drl_ctx* c, const drl_score_opts* o, int n_seg, int D, std::vector
     if (o->vae_center && !o->vae_scale) return fail(c, DRL_ERR_ARG, "opts.vae_center given without vae_scale");
     S = o->in_scale ? up16(n_seg) : 0;
     P = o->vae_center ? up32(D) : 0;      // padded to a whole 32-feature tile (center 0, 1/scale 1):
-    h.assign(2 * S + 4 * P, 0.0f);        // vae_wide_kernel streams them per tile
+    h.assign(2 * S + 4 * P, 0.0f);        // vae_wide16_kernel streams them per slab
     if (S) {
         memcpy(h.data(), o->in_scale, n_seg * sizeof(float));
         memcpy(h.data() + S, o->in_offset, n_seg * sizeof(float));
@@ -893,25 +960,38 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.x = d_series; a.win_stride = F; a.lag_elems = (1 - o->vae_lag) * F; a.D = W * F;
         a.rs = od.rs; a.rsP = od.rsP; a.clip = o->vae_clip;
         a.eps = d_eps; a.seg = seg; a.n_tiles = sh.tiles32; a.err = d_err; a.recon = nullptr;
-        // wide windows: stream the first/last layer through LDS when the windows' flat region fits
-        const int xr_floats = (31 * F + ((W * F + 31) & ~31) + 3) & ~3;
-        const size_t wide_lds = ((size_t)2 * VW_WT + 2 * VW_SIDE + (size_t)4 * xr_floats) * sizeof(float);
-        const bool wide = W * F > 128 && !d_eps && wide_lds <= 160 * 1024 &&
-                          c->vae.dout[0] > 96 && c->vae.dout[0] <= 128 &&
-                          c->vae.din[c->vae.n_path - 1] > 96 && c->vae.din[c->vae.n_path - 1] <= 128;
+        // wide windows: stream the first/last layer through LDS when the workgroup's flat region fits
+        const int xr_floats = (63 * F + ((W * F + 31) & ~31) + 3) & ~3;
+        size_t wide_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
+        if (const char* e = getenv("DRLVAE_VW16_PAD")) wide_lds = std::min<size_t>(wide_lds + (size_t)atoi(e), 160 * 1024);   // measurement knob: fewer workgroups per CU
+        const bool wide = c->vae.wide16 && !d_eps && wide_lds <= 160 * 1024;
         if (prof) prof_begin(c, 1, vst);
         if (wide) {
             if (wide_lds > c->wide_lds_set) {
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide_kernel<true>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide_kernel<false>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 c->wide_lds_set = 160 * 1024;
             }
-            const dim3 grid((sh.tiles32 + 3) / 4);
-            if (a.rs) hipLaunchKernelGGL(vae_wide_kernel<true>, grid, dim3(256), wide_lds, vst, a, xr_floats);
-            else hipLaunchKernelGGL(vae_wide_kernel<false>, grid, dim3(256), wide_lds, vst, a, xr_floats);
-            c->last_vae_variant = "wide";
+            Vae16Args b16;
+            memset(&b16, 0, sizeof b16);
+            for (int p = 0; p < c->vae.n_path; ++p) {
+                b16.w16[p] = (const float*)c->vae_w.p + c->vae.w16_off[p];
+                b16.b16[p] = (const float*)c->vae_w.p + c->vae.b16_off[p];
+            }
+            {
+                // the middle layers' weights and biases are contiguous in the pack: staged into the ring when they fit
+                const int lastp = c->vae.n_path - 1;
+                const size_t span = lastp > 1 ? c->vae.w16_off[lastp] - c->vae.w16_off[1] : 0;
+                b16.mid_floats = (span > 0 && span <= 2 * VW16_SLAB && span % 4 == 0) ? (int)span : 0;
+            }
+            a.seg.tile_off = sh.d_t64;               // a workgroup = one 64-window tile
+            a.n_tiles = sh.tiles64;
+            const dim3 grid(sh.tiles64);
+            if (a.rs) hipLaunchKernelGGL(vae_wide16_kernel<true>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);
+            else hipLaunchKernelGGL(vae_wide16_kernel<false>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);
+            c->last_vae_variant = "wide16";
         } else {
             int rcl = launch_vae_chain(c, a, sh.tiles32, vst);
             if (rcl) return rcl;

@@ -13,7 +13,7 @@
 //
 // Kernels, in file order (DESIGN.md section 4 has the table with shapes and bounds):
 //   vae_kernel<MAXT>            VAE chain, narrow windows / explicit batches / eps path
-//   vae_wide_kernel<SCALED>     VAE, wide windows: LDS-staged windows, weights through an LDS ring
+//   (vae_wide16.hip.h)          vae_wide16_kernel<SCALED>: VAE, wide windows — LDS-staged windows, weights through an LDS ring
 //   lstm_generic_kernel<NT>     fallback LSTM (whole cell per wave, weights from L2)
 //   xproj_kernel<NT>            input projections once per sample
 //   lstm_rec_kernel<NT,FLAGGED> recurrence from the projections, H <= 64
@@ -25,7 +25,7 @@
 // lstm_w16.hip.h adds lstm_h128i2_w16_kernel: the univariate recurrence on 16-window tiles
 // (v_mfma_f32_16x16x4_f32) for calls too small to fill the chip with 32-window tiles.
 // lstm_f16x3.hip.h adds the opt-in 3-term f16-split variant of lstm_h128i2_kernel.
-// VW_ABL / H128_ABL / REC_ABL are timing-only ablation switches (wrong results) used to price the parts of a
+// VW16_ABL / H128_ABL / REC_ABL are timing-only ablation switches (wrong results) used to price the parts of a
 // kernel; the default build has them off.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -429,252 +429,6 @@ __global__ __launch_bounds__(256, (LDSW ? 1 : (MAXT <= 2 ? 3 : 1))) void vae_ker
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// K2, wide windows (D = W*F in the hundreds or thousands: SMD 950, WaDi 3075).  The first and the
-// last Dense layer are real GEMMs here ([windows, D] x [D, 128] and back), so their weights are
-// streamed tile by tile (16 KiB = one 32-feature slab x 128 hidden, contiguous in the packed
-// layout) through a double-buffered LDS ring shared by the workgroup's four waves, and each
-// wave's windows are staged ONCE into LDS as the contiguous flat region they overlap in
-// (32 windows of D elements at stride F = (31*F + D) floats), with coalesced loads.  B fragments
-// are then LDS reads at lane stride F (conflict-free for odd F), RobustScaler/clip applied on the
-// fly.  The narrow middle layers chain in registers as in vae_kernel.
-#define VW_WT 4096     // floats per staged weight tile
-#ifndef VW_WAVES_PER_SIMD
-#define VW_WAVES_PER_SIMD 2
-#endif
-#ifndef VW_ABL
-#define VW_ABL 0      // timing-only ablations (wrong results): 1 every staged tile is tile 0, 2 no global loads,
-                      // 3 no barriers, 4 no last-layer epilogue, 5 no layer-0 input transform
-#endif
-__device__ __forceinline__ void vw_stage_load(f32x4 (&reg)[4], const float* __restrict__ src) {
-#if VW_ABL == 2
-    return;
-#endif
-    const f32x4* p = reinterpret_cast<const f32x4*>(src) + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) reg[i] = p[i * 256];
-}
-__device__ __forceinline__ void vw_stage_store(const f32x4 (&reg)[4], float* dst) {
-    f32x4* p = reinterpret_cast<f32x4*>(dst) + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i * 256] = reg[i];
-}
-// side tile of feature tile `ft`: c_hi[32] | c_lo[32] | inv_hi[32] | inv_lo[32] | packed bias[32].
-// Every thread owns one stream (a base pointer chosen once, advanced 32 floats per tile) so the
-// per-tile load is a single unconditional global_load: the scaler table is padded to a multiple of 32
-// columns on the host and the packed bias is tile-padded by construction.  Threads with nothing to
-// fetch re-read a valid dummy word.
-#define VW_SIDE 160
-__device__ __forceinline__ const float* vw_side_stream(const VaeArgs& a, const float* __restrict__ bias_p, bool scaled) {
-    const int t = threadIdx.x;
-    if (scaled && t < 128) return a.rs + (size_t)(t >> 5) * a.rsP + (t & 31);
-    if (bias_p && t >= 128 && t < 160) return bias_p + (t - 128);
-    return a.w[0];
-}
-
-// Hidden width is fixed at 4 tiles (97..128, zero padded) so that the 64 MFMAs of a weight tile
-// are straight-line code; SCALED selects the RobustScaler/clip transform at compile time.
-#if VW_ABL == 3
-#define VW_SYNC() do { } while (0)
-#else
-#define VW_SYNC() __syncthreads()
-#endif
-// Last-layer epilogue of one 32-feature output tile: activation, input transform, squared error.
-template <bool SCALED, int ACT, bool MASKED>
-__device__ __forceinline__ float vw_epilogue(const f32x16& acc, const float (&xv)[16], const float (&rsv)[4][16],
-                                             float clip, int d0, int D, int half, float sq) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float y = apply_act(acc[r], ACT);
-        float x = xv[r];
-        if (SCALED) x = robust_apply(x, rsv[0][r], rsv[1][r], rsv[2][r], rsv[3][r], clip);
-        float df = y - x;
-        if (MASKED) df = (d0 + rowmap(r, half) < D) ? df : 0.0f;      // the feature tail of the last tile is padding
-        sq = fmaf(df, df, sq);
-    }
-    return sq;
-}
-
-template <bool SCALED>
-__global__ __launch_bounds__(256, VW_WAVES_PER_SIMD) void vae_wide_kernel(VaeArgs a, int xr_floats) {
-    extern __shared__ __attribute__((aligned(16))) float vw_smem[];
-    float* wt = vw_smem;                         // [2][VW_WT]
-    float* side = vw_smem + 2 * VW_WT;           // [2][VW_SIDE]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, j = lane & 31;
-    float* xr = vw_smem + 2 * VW_WT + 2 * VW_SIDE + (size_t)wave * xr_floats;
-    const int tile = blockIdx.x * 4 + wave;
-    const bool active = tile < a.n_tiles;        // wave-uniform; idle waves still stage and sync
-    const float clip = a.clip > 0.0f ? a.clip : 3.0e38f;
-    const int D = a.D;
-
-    int count = 0, jj = 0;
-    long long wout = 0;
-    if (active) {
-        const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
-        const long long samp0 = a.seg.samp_off[s];
-        const long long nsamp = a.seg.samp_off[s + 1] - samp0;
-        const long long Ks = a.seg.win_off[s + 1] - a.seg.win_off[s];
-        const long long k0 = (long long)(tile - a.seg.tile_off[s]) * 32;
-        count = (int)(Ks - k0 < 32 ? Ks - k0 : 32);
-        jj = j < count ? j : count - 1;
-        wout = a.seg.win_off[s] + k0 + jj;
-        const bool has_norm = a.seg.in_scale != nullptr;
-        const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
-        const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
-        // flat region of this wave's windows, clamped to the series, zero beyond it (the padded
-        // feature tail of the last tile is read, against zero weights, so it must be finite)
-        const long long e0 = samp0 * a.win_stride + a.lag_elems + k0 * a.win_stride;
-        const long long e_end = (samp0 + nsamp) * a.win_stride;
-        const int len = (int)((count - 1) * a.win_stride + D);
-        const float* __restrict__ src = a.x + e0;
-        for (int i = lane; i < xr_floats; i += 64) {
-            float v = (i < len && e0 + i < e_end) ? src[i] : 0.0f;
-            if (has_norm) v = minmax_apply(v, sc, of);
-            xr[i] = v;
-        }
-    }
-    const float* xw = xr + (size_t)jj * a.win_stride;     // this lane's window inside the region
-
-    f32x16 cur[4], nxt[4];
-    f32x4 stg[4];
-
-    // ---- layer 0: D -> hidden, weights streamed per 32-feature input tile
-    {
-        const int nin = (a.din[0] + 31) >> 5;
-        const float* __restrict__ w = a.w[0];
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot) cur[ot] = load_bias16(a.b[0], ot, half);
-        const float* __restrict__ ss = vw_side_stream(a, nullptr, SCALED);
-        vw_stage_load(stg, w);
-        vw_stage_store(stg, wt);
-        if (threadIdx.x < VW_SIDE) side[threadIdx.x] = ss[0];
-        __syncthreads();
-        for (int it = 0; it < nin; ++it) {
-            const int cb = it & 1;
-            const bool more = it + 1 < nin;
-            float side_next = 0.0f;
-            if (more) {
-                if (SCALED) side_next = ss[(it + 1) * 32];
-                vw_stage_load(stg, w + (size_t)(it + 1) * VW_WT);
-            }
-            if (active) {
-                const float* __restrict__ wb = wt + cb * VW_WT + lane;
-                const float* __restrict__ sb = side + cb * VW_SIDE;
-                const float* __restrict__ xt = xw + it * 32;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dl = rowmap(r, half);
-                    float bv = xt[dl];
-                    if (SCALED && VW_ABL != 5) bv = robust_apply(bv, sb[dl], sb[32 + dl], sb[64 + dl], sb[96 + dl], clip);
-#pragma unroll
-                    for (int ot = 0; ot < 4; ++ot) cur[ot] = mfma32(wb[(ot * 16 + r) * 64], bv, cur[ot]);
-                }
-            }
-            if (more) {
-                vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
-                if (threadIdx.x < VW_SIDE) side[(cb ^ 1) * VW_SIDE + threadIdx.x] = side_next;
-            }
-            VW_SYNC();
-        }
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot) act16(cur[ot], a.act[0]);
-    }
-
-    // ---- middle layers: registers -> registers, small weights straight from L2
-    for (int p = 1; p < a.n - 1; ++p) {
-        const int nin = (a.din[p] + 31) >> 5, nout = (a.dout[p] + 31) >> 5;
-        const float* __restrict__ w = a.w[p];
-        if (active) {
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-                nxt[ot] = ot < nout ? load_bias16(a.b[p], ot, half) : f32x16{};
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (it < nin) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                        for (int ot = 0; ot < 4; ++ot)
-                            if (ot < nout)
-                                nxt[ot] = mfma32(w[(((size_t)ot * nin + it) * 16 + r) * 64 + lane], cur[it][r], nxt[ot]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) { cur[ot] = nxt[ot]; act16(cur[ot], a.act[p]); }
-        }
-    }
-
-    // ---- last layer: hidden -> D, weights streamed per 32-feature output tile, error fused
-    {
-        const int p = a.n - 1;
-        const int nout = (a.dout[p] + 31) >> 5;
-        const float* __restrict__ w = a.w[p];
-        const int act = a.act[p];
-        float sq = 0.0f;
-        const float* __restrict__ ss = vw_side_stream(a, a.b[p], SCALED);
-        vw_stage_load(stg, w);
-        vw_stage_store(stg, wt);
-        if (threadIdx.x < VW_SIDE) side[threadIdx.x] = ss[0];
-        __syncthreads();
-        for (int ot = 0; ot < nout; ++ot) {
-            const int cb = ot & 1;
-            const bool more = ot + 1 < nout;
-            float side_next = 0.0f;
-            if (more) {
-                side_next = ss[(ot + 1) * 32];
-                vw_stage_load(stg, w + (size_t)(ot + 1) * VW_WT);
-            }
-            if (active) {
-                const float* __restrict__ wb = wt + cb * VW_WT + lane;
-                const float* __restrict__ sb = side + cb * VW_SIDE;
-                const float* __restrict__ xt = xw + ot * 32;
-                // everything the tile reads from LDS is requested before its first MFMA (bias first,
-                // it initialises the accumulator), so the LDS latency is paid once per tile and the
-                // epilogue's operands arrive under the MFMAs
-                f32x16 acc = load_bias16(sb + 128, 0, half);
-                float av[64], xv[16], rsv[4][16];
-#pragma unroll
-                for (int i = 0; i < 64; ++i) av[i] = wb[i * 64];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dl = rowmap(r, half);
-                    xv[r] = xt[dl];
-                    if (SCALED) { rsv[0][r] = sb[dl]; rsv[1][r] = sb[32 + dl]; rsv[2][r] = sb[64 + dl]; rsv[3][r] = sb[96 + dl]; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc = mfma32(av[it * 16 + r], cur[it][r], acc);
-#if VW_ABL == 4
-                sq += acc[0] + acc[15] + xv[0];
-#else
-                // activation code and "is this the padded last tile" are wave-uniform: one straight-line
-                // epilogue per combination, no per-element selects or copies
-                const bool masked = ot + 1 == nout;
-                if (act == 3) sq = masked ? vw_epilogue<SCALED, 3, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
-                                          : vw_epilogue<SCALED, 3, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
-                else if (act == 2) sq = masked ? vw_epilogue<SCALED, 2, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
-                                               : vw_epilogue<SCALED, 2, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
-                else if (act == 1) sq = masked ? vw_epilogue<SCALED, 1, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
-                                               : vw_epilogue<SCALED, 1, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
-                else sq = masked ? vw_epilogue<SCALED, 0, true>(acc, xv, rsv, clip, ot * 32, D, half, sq)
-                                 : vw_epilogue<SCALED, 0, false>(acc, xv, rsv, clip, ot * 32, D, half, sq);
-#endif
-            }
-            if (more) {
-                vw_stage_store(stg, wt + (cb ^ 1) * VW_WT);
-                if (threadIdx.x < VW_SIDE) side[(cb ^ 1) * VW_SIDE + threadIdx.x] = side_next;
-            }
-            VW_SYNC();
-        }
-        sq += __shfl_xor(sq, 32);
-        if (active && a.err && half == 0 && j < count) a.err[wout] = sq / (float)D;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // K3: LSTM-DQN.
