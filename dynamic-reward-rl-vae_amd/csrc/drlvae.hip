@@ -103,6 +103,9 @@ struct drl_ctx {
     int overlap_mode = 1;         // 0 never, 1 large wide-window calls, 2 always (DRLVAE_OVERLAP)
     int gemv_rounds = -1;         // estimator.predict batches of up to this many states per CU take the matrix-vector kernel
                                   // (DRLVAE_GEMV_ROUNDS; -1: 4 for the univariate H > 64 net, 8 for the others)
+    int rollout_mode = 0;         // drl_rollout_batch: 0 auto, 1 fixed-point over full-parallel passes, 2 one persistent
+                                  // workgroup per series (DRLVAE_ROLLOUT / drl_set_rollout_mode)
+    size_t rollout_lds_set = 0;
     int rec2_mode = 1;            // two candidate states in one wave: 0 never, 1 whole rounds of tiles, 2 always (DRLVAE_REC2)
     bool last_overlap = false;
     std::string err;
@@ -460,6 +463,7 @@ int drl_create(int device_id, drl_ctx** out) {
     if (const char* e = getenv("DRLVAE_FORCE_GENERIC")) c->force_generic = atoi(e) != 0;
     if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
     if (const char* e = getenv("DRLVAE_REC2")) c->rec2_mode = atoi(e);
+    if (const char* e = getenv("DRLVAE_ROLLOUT")) c->rollout_mode = std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("DRLVAE_GEMV_ROUNDS")) c->gemv_rounds = std::max(0, atoi(e));
     *out = c;
     return DRL_OK;
@@ -504,6 +508,13 @@ int drl_set_lstm_math(drl_ctx* c, int mode) {
     if (!c) return DRL_ERR_ARG;
     if (mode != 0 && mode != 1) return fail(c, DRL_ERR_ARG, "drl_set_lstm_math: mode %d (0 = fp32, 1 = f16x3)", mode);
     c->lstm_math = mode;
+    return DRL_OK;
+}
+
+int drl_set_rollout_mode(drl_ctx* c, int mode) {
+    if (!c) return DRL_ERR_ARG;
+    if (mode < 0 || mode > 2) return fail(c, DRL_ERR_ARG, "drl_set_rollout_mode: mode %d (0 auto, 1 fixed point, 2 sequential kernel)", mode);
+    c->rollout_mode = mode;
     return DRL_OK;
 }
 
@@ -1481,6 +1492,59 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
     if ((rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t) + 64))) return rc;
     if ((rc = ensure(c, c->st_margin, 256))) return rc;             // the "changed" word
     HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    // Two exact designs (measured: tools/rollout_time.py -> profiles/r2/rollout_time.txt):
+    //  * fixed point over full-parallel scoring passes: as many passes as the busiest series has runs of
+    //    action changes (+1), each as long as one scoring call of the whole batch (0.15 ms for one Yahoo
+    //    series, 2.4 ms for all 67) — 8 to 90 times faster than stepping on the validation sets;
+    //  * sequential kernel: one persistent workgroup per series, W dependent matrix-vector steps per cursor
+    //    (22.5 us at W = 25), whatever the actions are, series in parallel one per CU: 32 ms for any batch of
+    //    Yahoo-length series — 2.5 times faster than the fixed point on all 67 A1 series (33 passes).
+    // Auto starts with the fixed point and hands over to the sequential kernel once the passes made have cost
+    // what the sequential kernel would (its time is known in advance): never more than twice the better one.
+    long long longest = 0;
+    for (int i = 0; i < n_seg; ++i) longest = std::max<long long>(longest, seg_offsets[i + 1] - seg_offsets[i] - W);
+    const size_t seq_lds = (size_t)W * 32 * c->lstm.NT * sizeof(float);
+    const bool seq_ok = seq_lds <= 150 * 1024;
+    if (c->rollout_mode == 2 && !seq_ok)
+        return fail(c, DRL_ERR_UNSUPPORTED, "drl_rollout_batch: the sequential kernel holds W*%d floats in LDS (W = %d is too long)", 32 * c->lstm.NT, W);
+    const double seq_est_us = (double)longest * W * 0.9;
+    const double pass_est_us = std::max(150.0, (double)K * W * (c->lstm.NT == 16 ? 0.00105 : 0.0006));
+    const int pass_budget = (c->rollout_mode == 0 && seq_ok) ? (int)std::max(2.0, seq_est_us / pass_est_us) : 0x7fffffff;
+    auto run_sequential = [&]() -> int {
+        SegHost sh;
+        if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
+        OptDev od;
+        if (in_scale) {
+            drl_score_opts oo;
+            memset(&oo, 0, sizeof oo);
+            oo.in_scale = in_scale; oo.in_offset = in_offset;
+            if ((rc = upload_opts(c, &oo, n_seg, W, od))) return rc;
+        }
+        RolloutSeqArgs ra;
+        memset(&ra, 0, sizeof ra);
+        fill_lstm_args(c, ra.l);
+        ra.l.W = W; ra.l.x = (const float*)c->st_in.p;
+        ra.l.seg.samp_off = sh.d_samp; ra.l.seg.win_off = sh.d_win; ra.l.seg.tile_off = sh.d_t32; ra.l.seg.n_seg = n_seg; ra.l.seg.W = W;
+        ra.l.seg.in_scale = od.in_scale; ra.l.seg.in_offset = od.in_offset;
+        ra.action = (int*)c->st_act.p;
+        ra.q = q ? (float*)c->st_q.p : nullptr;
+        if (seq_lds > c->rollout_lds_set) {
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_seq_kernel<8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_seq_kernel<16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            c->rollout_lds_set = 150 * 1024;
+        }
+        if (c->lstm.NT == 8) hipLaunchKernelGGL(rollout_seq_kernel<8>, dim3(n_seg), dim3(256), seq_lds, c->stream, ra);
+        else hipLaunchKernelGGL(rollout_seq_kernel<16>, dim3(n_seg), dim3(512), seq_lds, c->stream, ra);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(action, c->st_act.p, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (q) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)K * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->last_variant = "rollout_seq";
+        return DRL_OK;
+    };
+    if (c->rollout_mode == 2) return run_sequential();     // *passes_out stays 0: no parallel passes were made
     drl_score_opts o;
     memset(&o, 0, sizeof o);
     o.struct_size = sizeof o; o.vae_lag = 1; o.flag_mode = DRL_FLAG_EXPLICIT; o.action_rule = DRL_ACTION_ARGMAX;
@@ -1512,6 +1576,11 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
         HIP_TRY(c, hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!changed) break;
+        if (passes >= pass_budget) {
+            // auto: the passes so far have cost what stepping through the series costs — finish that way
+            if (passes_out) *passes_out = passes;
+            return run_sequential();
+        }
         if (passes > max_K + 1)
             return fail(c, DRL_ERR_STATE, "drl_rollout_batch: no fixed point after %d passes", passes);
     }

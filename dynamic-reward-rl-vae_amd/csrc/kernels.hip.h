@@ -1426,6 +1426,111 @@ __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sequential validator rollout, one persistent workgroup per series (reference myasp-A1.py:471-496
+// driving env.reset / env.step, env.py:82-94, 126-151).  The policy's state at cursor
+// c = k + W is rows (v[n], flag[n]) of samples n = k+1 .. k+W, where flag[W] = 1 (the initial state's
+// last row, myasp-A1.py:126) and flag[n] = the action taken at cursor n - 1 for n > W: the action is
+// written straight into the next sample's flag, in LDS.  Every window is a fresh W-step recurrence from
+// h = c = 0, so the work per cursor is that of estimator.predict on one state — the matrix-vector form
+// of lstm_gemv_kernel (thread r owns gate row r, its recurrent weights in registers, h_t broadcast from
+// LDS, every sum in the MFMA kernels' order: bit-identical Q) — but the input side of a sample,
+// bias + wx_v*v[n] + wx_f*flag[n], is computed once when the sample enters the window and kept in an LDS
+// ring of W rows.  Series run in parallel, one per CU; a series costs N * W dependent steps whatever
+// its actions are (the fixed-point iteration of drl_rollout_batch costs one full-parallel pass per
+// action change instead: which is faster depends on the data, tools/rollout_time.py).
+struct RolloutSeqArgs {
+    LstmArgs l;              // weights, W, seg (samp_off / win_off / in_scale / in_offset), x = the series
+    int* action;             // [K_total]
+    float* q;                // [K_total, A] or null
+};
+template <int NT>
+__global__ __launch_bounds__(32 * NT, 1) void rollout_seq_kernel(RolloutSeqArgs ra) {
+    constexpr int ROWS = 32 * NT, HP = 8 * NT;
+    const LstmArgs& a = ra.l;
+    extern __shared__ __attribute__((aligned(16))) float rs_zx[];   // [W][ROWS]: input part of each sample in the window
+    __shared__ __attribute__((aligned(16))) float s_h[2][HP];
+    __shared__ float s_part[2 * 8];
+    __shared__ int s_act;
+    const int r = threadIdx.x;
+    const int tau = r >> 5, i = r & 31;
+    const int s = blockIdx.x;
+    const int W = a.W;
+    const long long samp0 = a.seg.samp_off[s];
+    const long long nsamp = a.seg.samp_off[s + 1] - samp0;
+    const long long K = nsamp - W;
+    if (K <= 0) return;                                   // block-uniform
+    const long long win0 = a.seg.win_off[s];
+    const bool has_norm = a.seg.in_scale != nullptr;
+    const float sc = has_norm ? a.seg.in_scale[s] : 1.0f;
+    const float of = has_norm ? a.seg.in_offset[s] : 0.0f;
+    const float* __restrict__ x = a.x + samp0;
+    auto value = [&](long long n) -> float {
+        const float v = x[n];
+        return has_norm ? minmax_apply(v, sc, of) : v;
+    };
+    float U[HP];
+#pragma unroll
+    for (int u = 0; u < HP; ++u) {
+        const int kk = (u >> 3) * 4 + ((u & 7) >> 1), half = u & 1;
+        U[u] = a.u[((size_t)kk * NT + tau) * 64 + half * 32 + i];
+    }
+    // packed layouts as in lstm_gemv_kernel: bias [NT][2][16], wx [ceil(I/2)][NT][64] = (f >> 1, tau, (f & 1)*32 + i)
+    const float bias = a.bias[(tau * 2 + ((i >> 2) & 1)) * 16 + (i & 3) + 4 * (i >> 3)];
+    const float w_v = a.wx[(size_t)tau * 64 + i], w_f = a.wx[(size_t)tau * 64 + 32 + i];
+    auto zx_of = [&](float v, float fl) -> float { return fmaf(w_f, fl, fmaf(w_v, v, bias)); };
+    for (int n = 1; n <= W; ++n) rs_zx[(n % W) * ROWS + r] = zx_of(value(n), n == W ? 1.0f : 0.0f);
+    if (r < HP) { s_h[0][r] = 0.0f; s_h[1][r] = 0.0f; }
+    __syncthreads();
+
+    for (long long k = 0; k < K; ++k) {
+        // the sample that enters the window at the next cursor: requested now, used after the action is known
+        const float v_next = k + 1 < K ? value(k + W + 1) : 0.0f;
+        float c = 0.0f;
+        int slot = (int)((k + 1) % W);
+        for (int t = 0; t < W; ++t) {
+            const float* __restrict__ hs = s_h[t & 1];
+            float z = rs_zx[slot * ROWS + r];
+            slot = slot + 1 == W ? 0 : slot + 1;
+            if (t > 0) {
+#pragma unroll
+                for (int u = 0; u < HP; ++u) z = fmaf(U[u], hs[u], z);
+            }
+            const float hv = lstm_cell(quad_bcast<0>(z), quad_bcast<1>(z), quad_bcast<2>(z), quad_bcast<3>(z), a.forget_bias, c);
+            if ((i & 3) == 0) s_h[(t + 1) & 1][8 * tau + (i >> 2)] = hv;
+            __syncthreads();
+        }
+        // Q head in the order of the MFMA kernels: even and odd units as two chains, then their sum
+        const float* __restrict__ hs = s_h[W & 1];
+        if (r < 2 * a.A) {
+            const int act = r >> 1, half = r & 1;
+            float part = 0.0f;
+            for (int kk = 0; kk < 4 * NT; ++kk) {
+                const int unit = (kk >> 2) * 8 + 2 * (kk & 3) + half;
+                part = fmaf(hs[unit], unit < a.H ? a.w_out[unit * a.A + act] : 0.0f, part);
+            }
+            s_part[r] = part;
+        }
+        __syncthreads();
+        if (r == 0) {
+            // np.argmax, ties -> the first (reference myasp-A1.py:226-227), on the same floats drl_score_batch writes
+            int best = 0;
+            float bv = 0.0f;
+            for (int act = 0; act < a.A; ++act) {
+                const float qv = (s_part[2 * act] + s_part[2 * act + 1]) + a.b_out[act];
+                if (ra.q) ra.q[(win0 + k) * a.A + act] = qv;
+                if (act == 0 || qv > bv) { bv = qv; best = act; }
+            }
+            ra.action[win0 + k] = best;
+            s_act = best;
+        }
+        __syncthreads();
+        // the action becomes the flag of the sample that enters next (env.py:143-147); its slot is the one sample k+1 leaves
+        if (k + 1 < K) rs_zx[(int)((k + W + 1) % W) * ROWS + r] = zx_of(v_next, (float)s_act);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // action + AL margin from Q (reference myasp-A1.py:227, 255; myasp-wadi.py:328)
 __global__ void finalize_kernel(const float* __restrict__ q, long long K, int S, int A, int rule,
                                 int* __restrict__ action, float* __restrict__ margin) {

@@ -17,7 +17,7 @@ COMM_ID_BYTES = 128
 SYMBOLS = [
     "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
     "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_batch_dev_noalloc", "drl_score_series",
-    "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
+    "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_set_rollout_mode", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
     "drl_last_lstm_variant", "drl_last_lstm_tile", "drl_last_call_overlapped",
     "drl_comm_unique_id", "drl_comm_init", "drl_allgather_scores", "drl_comm_destroy",
 ]
@@ -90,6 +90,7 @@ def load():
     lib.drl_set_stream.argtypes = [vp, vp]
     lib.drl_synchronize.argtypes = [vp]
     lib.drl_set_lstm_math.argtypes = [vp, C.c_int]
+    lib.drl_set_rollout_mode.argtypes = [vp, C.c_int]
     lib.drl_set_vae.argtypes = [vp, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int,
                                 C.POINTER(vp), C.POINTER(vp), C.c_float]
     lib.drl_set_lstm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]

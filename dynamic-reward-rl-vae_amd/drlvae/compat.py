@@ -191,15 +191,26 @@ class RewardFunction:
         self.tn, self.tp, self.fp, self.fn = tn, tp, fp, fn
         self.include = include_vae_penalty
         self.label_column = label_column
-        self._cache: Dict[int, np.ndarray] = {}
+        self._cache: Dict[tuple, np.ndarray] = {}
+        self.max_cached_series = 256
+
+    def clear(self):
+        """Forget every cached series (call after re-training the VAE in place)."""
+        self._cache.clear()
 
     def errors_for(self, timeseries) -> np.ndarray:
-        key = id(timeseries)
-        if key not in self._cache:
-            v = np.asarray(timeseries["value"], dtype=np.float32)
+        # keyed on the CONTENT of the value column (length + a hash of its bytes) and on the VAE the errors
+        # were computed with: an id() can be reused after garbage collection, a frame can be edited in place
+        v = np.ascontiguousarray(np.asarray(timeseries["value"], dtype=np.float32))
+        key = (len(v), hash(v.tobytes()), id(self.vae), id(self.vae.config))
+        err = self._cache.get(key)
+        if err is None:
             self.vae._bind()
-            self._cache[key] = self.vae.scorer.score(v, self.W, vae_lag=1, want=("err",))["err"]
-        return self._cache[key]
+            err = self.vae.scorer.score(v, self.W, vae_lag=1, want=("err",))["err"]
+            if len(self._cache) >= self.max_cached_series:
+                self._cache.pop(next(iter(self._cache)))            # oldest entry
+            self._cache[key] = err
+        return err
 
     def __call__(self, timeseries, timeseries_curser, action=0, vae=None, dynamic_coef=1.0):
         c = timeseries_curser

@@ -287,35 +287,19 @@ def _layer_inputs(layer_cfg) -> List[str]:
     return names
 
 
-def load_keras_vae(path: str) -> dict:
-    """Read a reference VAE ``.h5`` into the flat dense-chain description ``drl_set_vae`` takes.
+def vae_topology(model_config: dict, where: str = "model_config") -> dict:
+    """The Dense chain of a reference VAE from its Keras ``model_config`` alone (no weights): which
+    Dense layers form the encoder, which are z_mean / z_log_var, the decoder layers in call order, their
+    activations and the log-variance clip.
 
-    The topology comes from the file's ``model_config`` (not from the driver script: the committed
-    ``vae_model.h5`` has two encoder hidden layers where myasp-A1.py:89-91 builds three, SURVEY.md
-    §2 row 17).  The sampling layer (class ``Sampling``, or the WaDi ``Lambda``) names its inputs
-    [z_mean, clipped z_log_var]; the mean path follows z_mean.  Nested sub-models (the WaDi
-    ``decoder``, myasp-wadi.py:111-117) are flattened in call order.
+    The sampling layer (class ``Sampling``, myasp-A1.py:78-84, or the WaDi ``Lambda``,
+    myasp-wadi.py:106-108) names its inputs [z_mean, clipped z_log_var]; the mean path follows z_mean.
+    Nested sub-models (the WaDi ``decoder``, myasp-wadi.py:111-117) are flattened in call order.
 
-    Returns {"dims", "acts", "kernels", "biases", "mu_layer", "logvar_layer", "logvar_clip",
-    "layer_names", "keras_version"} with layers ordered: encoder hidden..., mu, logvar,
-    decoder hidden..., output.
+    Returns {"layer_names", "acts", "mu_layer", "logvar_layer", "logvar_clip"} with layers ordered
+    encoder hidden..., mu, logvar, decoder hidden..., output.
     """
-    f = H5File(path)
-    root_attrs = f.attrs(f.root_header)
-    if "model_config" not in root_attrs:
-        raise H5Error(f"{path}: no model_config attribute (weights-only files are not supported)")
-    cfg = json.loads(root_attrs["model_config"])
-    layers_cfg = cfg["config"]["layers"]
-
-    weights = f.walk_datasets("model_weights")
-
-    def dense_weights(name: str):
-        k = [p for p in weights if p.split("/")[-1].startswith("kernel") and f"/{name}/" in f"/{p}"]
-        bb = [p for p in weights if p.split("/")[-1].startswith("bias") and f"/{name}/" in f"/{p}"]
-        if len(k) != 1 or len(bb) != 1:
-            raise H5Error(f"{path}: cannot locate weights of layer {name!r}")
-        return f.read_dataset(weights[k[0]]).astype(np.float32), f.read_dataset(weights[bb[0]]).astype(np.float32)
-
+    layers_cfg = model_config["config"]["layers"]
     by_name = {l["name"]: l for l in layers_cfg}
     dense = {n: l for n, l in by_name.items() if l["class_name"] == "Dense"}
 
@@ -325,7 +309,7 @@ def load_keras_vae(path: str) -> dict:
             sampler = l
             break
     if sampler is None:
-        raise H5Error(f"{path}: no sampling layer with two inputs in model_config")
+        raise H5Error(f"{where}: no sampling layer with two inputs in model_config")
     s_in = _layer_inputs(sampler)
 
     def back_to_dense(name: str) -> str:
@@ -334,7 +318,7 @@ def load_keras_vae(path: str) -> dict:
         while name not in dense:
             ins = _layer_inputs(by_name[name])
             if not ins or seen > 8:
-                raise H5Error(f"{path}: cannot trace {name!r} back to a Dense layer")
+                raise H5Error(f"{where}: cannot trace {name!r} back to a Dense layer")
             name = ins[0]
             seen += 1
         return name
@@ -381,23 +365,43 @@ def load_keras_vae(path: str) -> dict:
 
     names = enc + [mu_name, lv_name] + [n for n, _ in dec]
     cfgs = [dense[n] for n in enc] + [dense[mu_name], dense[lv_name]] + [c for _, c in dec]
-    kernels, biases, acts = [], [], []
+    acts = []
     for n, c in zip(names, cfgs):
-        k, bvec = dense_weights(n)
         act = c["config"].get("activation", "linear")
         if act not in _ACTS:
-            raise H5Error(f"{path}: activation {act!r} of layer {n} not supported")
+            raise H5Error(f"{where}: activation {act!r} of layer {n} not supported")
+        acts.append(_ACTS[act])
+    return {"layer_names": names, "acts": acts, "mu_layer": len(enc), "logvar_layer": len(enc) + 1,
+            "logvar_clip": logvar_clip}
+
+
+def load_keras_vae(path: str) -> dict:
+    """Read a reference VAE ``.h5`` into the flat dense-chain description ``drl_set_vae`` takes.
+
+    The topology comes from the file's ``model_config`` (vae_topology; not from the driver script:
+    the committed ``vae_model.h5`` has two encoder hidden layers where myasp-A1.py:89-91 builds three,
+    SURVEY.md §2 row 17), the weights from ``/model_weights/<layer>/.../{kernel,bias}:0``.
+
+    Returns the vae_topology fields plus {"kernels", "biases", "keras_version", "backend"}.
+    """
+    f = H5File(path)
+    root_attrs = f.attrs(f.root_header)
+    if "model_config" not in root_attrs:
+        raise H5Error(f"{path}: no model_config attribute (weights-only files are not supported)")
+    topo = vae_topology(json.loads(root_attrs["model_config"]), path)
+    weights = f.walk_datasets("model_weights")
+
+    def dense_weights(name: str):
+        k = [p for p in weights if p.split("/")[-1].startswith("kernel") and f"/{name}/" in f"/{p}"]
+        bb = [p for p in weights if p.split("/")[-1].startswith("bias") and f"/{name}/" in f"/{p}"]
+        if len(k) != 1 or len(bb) != 1:
+            raise H5Error(f"{path}: cannot locate weights of layer {name!r}")
+        return f.read_dataset(weights[k[0]]).astype(np.float32), f.read_dataset(weights[bb[0]]).astype(np.float32)
+
+    kernels, biases = [], []
+    for n in topo["layer_names"]:
+        k, bvec = dense_weights(n)
         kernels.append(np.ascontiguousarray(k))
         biases.append(np.ascontiguousarray(bvec))
-        acts.append(_ACTS[act])
-    return {
-        "layer_names": names,
-        "kernels": kernels,
-        "biases": biases,
-        "acts": acts,
-        "mu_layer": len(enc),
-        "logvar_layer": len(enc) + 1,
-        "logvar_clip": logvar_clip,
-        "keras_version": root_attrs.get("keras_version"),
-        "backend": root_attrs.get("backend"),
-    }
+    return dict(topo, kernels=kernels, biases=biases, keras_version=root_attrs.get("keras_version"),
+                backend=root_attrs.get("backend"))

@@ -67,6 +67,11 @@ class WindowScorer:
         m = {"fp32": 0, "f16x3": 1}.get(mode, mode)
         self._check(self._lib.drl_set_lstm_math(self._h, int(m)), "drl_set_lstm_math")
 
+    def set_rollout_mode(self, mode):
+        """"auto" (default), "fixed_point" or "sequential": which exact design ``rollout`` runs."""
+        m = {"auto": 0, "fixed_point": 1, "sequential": 2}.get(mode, mode)
+        self._check(self._lib.drl_set_rollout_mode(self._h, int(m)), "drl_set_rollout_mode")
+
     # ------------------------------------------------------------------ weights
     def set_vae(self, vae: Dict):
         """vae: {"kernels", "biases", "acts", "mu_layer", "logvar_layer", "logvar_clip"} in the

@@ -195,6 +195,15 @@ int drl_q_predict(drl_ctx* ctx, const float* states, int64_t B, int W, float* q)
 int drl_rollout_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg, int W,
                       const float* in_scale, const float* in_offset,
                       int32_t* action, float* q, int32_t* passes_out);
+/* Which of the two exact designs drl_rollout_batch runs (no counterpart in the reference):
+ *   1  the fixed point over full-parallel scoring passes described above (passes_out = their number);
+ *   2  one persistent workgroup per series that steps through the cursors, the action written straight
+ *      into the next state's flag (passes_out = 0); series run in parallel, one per CU;
+ *   0  (default) starts as 1 and hands over to 2 once the passes made have cost what 2 would (known in
+ *      advance: 0.9 us per cursor and time step of the longest series): at most twice the better of the two.
+ *      passes_out = the passes made before the hand-over.
+ * Both give the sequential rollout's actions and the same Q, bit for bit.  Environment: DRLVAE_ROLLOUT. */
+int drl_set_rollout_mode(drl_ctx* ctx, int mode);
 
 /* ---- active-learning selection -------------------------------------------------------------------- */
 

@@ -34,12 +34,19 @@ def assert_q_close(got, want, what=""):
     assert rel.max() <= RTOL, f"{what}: max rel diff {rel.max():.3e}"
 
 
-def assert_actions(got, q_want, act_want):
+def assert_actions(got, q_want, act_want, max_flips=2):
+    """Actions are exact wherever the oracle's own margin exceeds the Q tolerance; inside that "unsafe" set
+    (|q0-q1| below 2e-5 max|Q|: the fp64 and fp32 oracles themselves may disagree there) the flips are
+    counted, printed and bounded.  Returns (unsafe, flips)."""
     q_want = np.asarray(q_want, np.float64)
+    got, act_want = np.asarray(got), np.asarray(act_want)
     margin = np.abs(q_want[..., 0] - q_want[..., 1])
     safe = margin > 2 * RTOL * np.abs(q_want).max(axis=-1)
-    assert np.array_equal(np.asarray(got)[safe], np.asarray(act_want)[safe])
-    assert (~safe).sum() <= max(2, len(safe) // 1000)
+    assert np.array_equal(got[safe], act_want[safe])
+    unsafe, flips = int((~safe).sum()), int((got[~safe] != act_want[~safe]).sum())
+    assert unsafe <= max(2, len(safe) // 1000)
+    assert flips <= max_flips, f"{flips} action flips among {unsafe} sub-tolerance windows"
+    return unsafe, flips
 
 
 def synth_lstm(rng, I, H, A=2):
@@ -157,7 +164,7 @@ def test_c2_all_a1_series_ragged_batch(scorer, a1, ckpt_a1):
     K = sum(len(s) - W for s in series)
     assert K == 93191 and out["err"].shape == (K,)
     pos = 0
-    n_unsafe = 0
+    n_unsafe = n_flips = n_flips32 = 0
     for s in series:
         r = orc.score_series_univariate(s, W, vae, lstm, "quirk", dtype=np.float64)
         k = len(s) - W
@@ -166,9 +173,18 @@ def test_c2_all_a1_series_ragged_batch(scorer, a1, ckpt_a1):
         margin = np.abs(r["q"][:, 0] - r["q"][:, 1])
         safe = margin > 2 * RTOL * np.abs(r["q"]).max(axis=1)
         n_unsafe += int((~safe).sum())
-        assert np.array_equal(out["action"][pos:pos + k][safe], r["action"][safe])
+        got = out["action"][pos:pos + k]
+        assert np.array_equal(got[safe], r["action"][safe])
+        n_flips += int((got[~safe] != r["action"][~safe]).sum())
+        if (~safe).any():
+            # the reference's own arithmetic is float32: how often does the fp32 oracle flip against the fp64 one there?
+            r32 = orc.score_series_univariate(s, W, vae, lstm, "quirk", dtype=np.float32)
+            n_flips32 += int((r32["action"][~safe] != r["action"][~safe]).sum())
         pos += k
+    print(f"C2: {n_unsafe} of {K} windows have |q0-q1| below the Q tolerance; actions differ from the fp64 oracle "
+          f"on {n_flips} of them (the fp32 numpy oracle differs on {n_flips32})")
     assert n_unsafe <= 20
+    assert n_flips <= 3                 # never outside the sub-tolerance set (asserted above), and almost never inside it
     # AL ranking (reference myasp-A1.py:250-259) from device margins, first series
     k0 = len(series[0]) - W
     r0 = orc.score_series_univariate(series[0], W, vae, lstm, "quirk", dtype=np.float32)
@@ -595,8 +611,17 @@ def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckp
     off = z["offsets"]
     lstm, _ = ckpt_a2
     scorer.set_lstm(lstm)
+    scorer.set_rollout_mode("fixed_point")
     acts, q = scorer.rollout(z["values"], W, off, return_q=True)
-    assert scorer.last_rollout_passes < 200
+    assert 0 < scorer.last_rollout_passes < 200
+    # the other exact design — one persistent workgroup per series, the action written straight into the next
+    # state's flag — gives the same actions and the same Q, bit for bit; auto picks it for a batch of nine series
+    scorer.set_rollout_mode("sequential")
+    acts_s, q_s = scorer.rollout(z["values"], W, off, return_q=True)
+    assert scorer.last_rollout_passes == 0 and scorer.lstm_variant == "rollout_seq"
+    assert np.array_equal(acts, acts_s) and np.array_equal(q.view(np.uint32), q_s.view(np.uint32))
+    scorer.set_rollout_mode("auto")          # nine series, two passes: the fixed point finishes long before its budget
+    assert np.array_equal(scorer.rollout(z["values"], W, off), acts) and scorer.last_rollout_passes == 2
     pos = 0
     for i, s in enumerate(series):
         k = len(s) - W
@@ -636,6 +661,34 @@ def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckp
     sc, of = orc.minmax_f32(raw)[1:]
     a_raw = scorer.rollout(raw, W, in_scale=[sc], in_offset=[of])
     assert np.array_equal(a_raw, scorer.rollout(a1["series"][0], W))
+    scorer.set_rollout_mode("sequential")
+    try:
+        assert np.array_equal(scorer.rollout(raw, W, in_scale=[sc], in_offset=[of]), a_raw)
+        # ragged batch with series too short to hold a window, W = 50 and a 64-unit network
+        rng = np.random.default_rng(77)
+        l64 = synth_lstm(rng, 2, 64)
+        scorer.set_lstm(l64)
+        lens = [130, 20, 50, 51, 400]
+        v = rng.random(sum(lens), dtype=np.float32)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        got_a, got_q = scorer.rollout(v, 50, offs, return_q=True)
+        scorer.set_rollout_mode("fixed_point")
+        want_a, want_q = scorer.rollout(v, 50, offs, return_q=True)
+        assert len(got_a) == 80 + 1 + 350 and np.array_equal(got_a, want_a)
+        assert np.array_equal(got_q.view(np.uint32), want_q.view(np.uint32))
+        assert np.array_equal(got_a[:80], orc.rollout_greedy(v[:130], 50, l64["kernel"], l64["bias"], l64["w_out"], l64["b_out"]))
+        # auto on all 67 A1 series (33 passes of 2.4 ms against 32 ms of stepping): hands over after its budget
+        scorer.set_lstm(lstm)
+        scorer.set_rollout_mode("auto")
+        flat = np.concatenate(a1["series"])
+        offs = np.concatenate([[0], np.cumsum([len(v) for v in a1["series"]])])
+        auto = scorer.rollout(flat, W, offs)
+        handed_over = scorer.lstm_variant == "rollout_seq"
+        scorer.set_rollout_mode("sequential")
+        assert np.array_equal(auto, scorer.rollout(flat, W, offs)) and handed_over and int(auto.sum()) == 1920
+    finally:
+        scorer.set_rollout_mode("auto")
+        scorer.set_lstm(lstm)
 
 
 # ----------------------------------------------------------------------------------- f16x3 split

@@ -217,6 +217,81 @@ def test_keras_hdf5_reader_on_the_reference_files(fname, shapes, acts, clip):
     assert all(np.isfinite(k).all() for k in v["kernels"])
 
 
+def test_keras_topology_of_a_wadi_shaped_nested_model():
+    """vae_topology on the model_config the WaDi driver's build_vae produces (reference myasp-wadi.py:101-117):
+    encoder Dense(128) -> z_mu / z_lv (clip_by_value) -> Lambda sampler -> a nested ``decoder`` sub-model.
+    ``vae_wadi.h5`` itself is absent from the reference tree, so the config is written out here in Keras 2.x
+    functional format; the nested-sub-model branch is what this exercises."""
+    from drlvae.formats.keras_h5 import H5Error, vae_topology
+
+    def node(*names):
+        return [[[n, 0, 0, {}] for n in names]]
+
+    def dense(name, units, act, inbound):
+        return {"class_name": "Dense", "name": name, "config": {"name": name, "units": units, "activation": act},
+                "inbound_nodes": inbound}
+
+    cfg = {"class_name": "Functional", "config": {"name": "vae", "layers": [
+        {"class_name": "InputLayer", "name": "input_1", "config": {"batch_input_shape": [None, 3075]}, "inbound_nodes": []},
+        dense("dense", 128, "relu", node("input_1")),
+        dense("dense_1", 10, "linear", node("dense")),
+        dense("dense_2", 10, "linear", node("dense")),
+        {"class_name": "TFOpLambda", "name": "tf.clip_by_value", "config": {"function": "clip_by_value"},
+         "inbound_nodes": [["dense_2", 0, 0, {"clip_value_min": -10.0, "clip_value_max": 10.0}]]},
+        {"class_name": "Lambda", "name": "lambda", "config": {}, "inbound_nodes": node("dense_1", "tf.clip_by_value")},
+        {"class_name": "Functional", "name": "decoder", "inbound_nodes": node("lambda"), "config": {"name": "decoder", "layers": [
+            {"class_name": "InputLayer", "name": "input_2", "config": {"batch_input_shape": [None, 10]}, "inbound_nodes": []},
+            dense("dense_3", 128, "relu", node("input_2")),
+            dense("dense_4", 3075, "sigmoid", node("dense_3"))]}},
+    ]}}
+    t = vae_topology(cfg)
+    assert t["layer_names"] == ["dense", "dense_1", "dense_2", "dense_3", "dense_4"]
+    assert t["acts"] == [1, 0, 0, 1, 2] and (t["mu_layer"], t["logvar_layer"]) == (1, 2) and t["logvar_clip"] == 10.0
+    # the univariate script's flat form with a Sampling layer and no clip (vae_model_kpi.h5's shape)
+    flat = {"config": {"layers": [
+        {"class_name": "InputLayer", "name": "in", "config": {}, "inbound_nodes": []},
+        dense("d0", 16, "relu", node("in")), dense("d1", 16, "relu", node("d0")),
+        dense("zm", 2, "linear", node("d1")), dense("zv", 2, "linear", node("d1")),
+        {"class_name": "Sampling", "name": "sampling", "config": {}, "inbound_nodes": node("zm", "zv")},
+        dense("d2", 16, "relu", node("sampling")), dense("out", 1, "linear", node("d2"))]}}
+    t = vae_topology(flat)
+    assert t["layer_names"] == ["d0", "d1", "zm", "zv", "d2", "out"] and t["mu_layer"] == 2 and t["logvar_clip"] == float("inf")
+    with pytest.raises(H5Error, match="sampling layer"):
+        vae_topology({"config": {"layers": [dense("d0", 4, "relu", [])]}})
+
+
+def test_reward_function_cache_is_keyed_on_content():
+    """compat.RewardFunction caches the per-series errors by the CONTENT of the value column and by the bound VAE
+    (an id() can be reused after garbage collection; a frame can be edited in place)."""
+    from drlvae import compat
+
+    class FakeScorer:
+        calls = 0
+
+        def score(self, v, W, **kw):
+            FakeScorer.calls += 1
+            return {"err": np.asarray(v[W:], np.float32) * 2}
+
+    class FakeVae:
+        config = {}
+        scorer = FakeScorer()
+
+        def _bind(self):
+            pass
+
+    rf = compat.RewardFunction(FakeVae(), 3)
+    a = {"value": np.arange(10, dtype=np.float32), "label": np.zeros(10)}
+    r1 = rf(a, 5, 0, dynamic_coef=1.0)
+    assert FakeScorer.calls == 1 and r1 == [1.0 + 10.0, -1.0 + 10.0]
+    rf(dict(a), 6, 0)                                   # another object, same content: no new scoring call
+    assert FakeScorer.calls == 1
+    a["value"][5] = 100.0                               # edited in place: must not return the stale error
+    assert rf(a, 5, 0, dynamic_coef=1.0) == [1.0 + 200.0, -1.0 + 200.0] and FakeScorer.calls == 2
+    rf.clear()
+    rf(a, 5, 0)
+    assert FakeScorer.calls == 3
+
+
 def test_tf_bundle_reader_on_every_reference_checkpoint():
     """Every TF1 Saver bundle the reference ships (20 runs; two naming schemes of the VAE layers,
     Q-net-only bundles, the I = 1 AdaptiveTauRL net): found, CRC32C-verified, shapes consistent.
