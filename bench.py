@@ -220,8 +220,9 @@ def pmc_traffic(name, variant):
     """HBM bytes per launch of the dominant kernel (the LSTM variant that ran) from the committed
     rocprofv3 PMC summary of the same workload (profiles/rNN/<workload>_pmc_summary.json, newest round),
     or None."""
-    kern = {"h128i2": "lstm_h128i2_kernel", "h128i2_f16x3": "lstm_h128i2_f16x3_kernel",
-            "xproj+rec": "lstm_rec", "xproj+h128": "lstm_h128p_kernel", "generic": "lstm_generic_kernel"}.get(variant, "lstm_")
+    kerns = {"h128i2": ["lstm_h128i2_kernel"], "h128i2_f16x3": ["lstm_h128i2_f16x3_kernel"],
+             "xproj+rec": ["xproj_kernel", "lstm_rec"], "xproj+h128": ["xproj_kernel", "lstm_h128p_kernel"],
+             "generic": ["lstm_generic_kernel"]}.get(variant, ["lstm_"])
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{name}_pmc_summary.json"))):
@@ -232,7 +233,7 @@ def pmc_traffic(name, variant):
         d = json.load(open(best))
         tot = 0.0
         for k, v in d["kernels"].items():
-            if kern in k and "hbm_bytes_per_launch" in v:
+            if any(kn in k for kn in kerns) and "hbm_bytes_per_launch" in v:
                 tot += v["hbm_bytes_per_launch"]
         return tot or None
     except Exception:

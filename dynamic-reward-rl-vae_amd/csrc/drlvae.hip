@@ -181,9 +181,12 @@ int fail(drl_ctx* c, int code, const char* fmt, ...) {
 
 int ensure(drl_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return DRL_OK;
-    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    // the new block first: a failed grow leaves the old one (and whatever it holds) in place
     size_t cap = std::max<size_t>(bytes, 256);
-    HIP_TRY(c, hipMalloc(&b.p, cap));
+    void* np = nullptr;
+    HIP_TRY(c, hipMalloc(&np, cap));
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
     b.cap = cap;
     return DRL_OK;
 }
@@ -993,6 +996,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             *P = (float*)(c->scratch_dev + DRL_SCRATCH_P_OFFSET);
             return DRL_OK;
         }
+        if (const char* e = getenv("DRLVAE_PBUF_MAX"))       // tests: behave as if a larger allocation had failed
+            if (bytes > (size_t)atoll(e)) return fail(c, DRL_ERR_HIP, "projections: %zu bytes over DRLVAE_PBUF_MAX", bytes);
         int r = ensure(c, c->pbuf, bytes);
         if (r) return r;
         *P = (float*)c->pbuf.p;
@@ -1075,6 +1080,20 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.q = d_q;
         // hidden widths 65..128 are packed zero-padded to 16 gate tiles x 64 k-steps (padded units stay at h = 0)
         const bool fast = c->lstm.I == 2 && c->lstm.NT == 16 && F == 1 && W >= 2 && W + 65 <= H128_SV;
+        // the other shapes project every sample once (1 KiB per sample for H <= 64, 2 KiB above: C4 177 MB).  When
+        // that buffer cannot be had — beyond 64 GiB, or the allocation fails — the call still runs, on the fallback
+        // kernel that re-projects every window's rows (the no-allocation entry point reports its limit instead).
+        float* Pbuf = nullptr;
+        bool use_proj = false;
+        if (!fast) {
+            const size_t per_sample = (size_t)c->lstm.NT * 32 * sizeof(float);
+            if ((size_t)seg_offsets[n_seg] * per_sample <= ((size_t)64 << 30)) {
+                rc = projections((size_t)seg_offsets[n_seg] * per_sample, &Pbuf);
+                if (rc == DRL_OK) use_proj = true;
+                else if (noalloc) return rc;
+                else (void)hipGetLastError();               // out of memory for the projections: fall back
+            }
+        }
         c->last_tile = 0;
         if (prof) prof_begin(c, 0, c->stream);
         if (fast && c->lstm_math == 1 && c->lstm.has_split) {
@@ -1105,14 +1124,10 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             c->last_variant = "h128i2"; c->last_tile = 64;
-        } else if (c->lstm.NT == 16 &&
-                   (size_t)seg_offsets[n_seg] * 2048 <= ((size_t)64 << 30)) {   // projections: 2 KiB per sample
+        } else if (c->lstm.NT == 16 && use_proj) {
             // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
             // recurrence from the projections
             const long long n_samples = seg_offsets[n_seg];
-            const size_t pbytes = (size_t)n_samples * 16 * 32 * sizeof(float);
-            float* Pbuf = nullptr;
-            if ((rc = projections(pbytes, &Pbuf))) return rc;
             XprojArgs xa;
             xa.x = d_series; xa.n_samples = n_samples; xa.F = F; xa.wx = a.wx; xa.bias = a.bias;
             xa.P = Pbuf; xa.nt_total = 16;
@@ -1132,13 +1147,9 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 hipLaunchKernelGGL(lstm_h128p_kernel<2>, dim3(gx, a.S), dim3(256), 0, c->stream, ra);
             }
             c->last_variant = "xproj+h128";
-        } else if (c->lstm.NT == 8 &&
-                   (size_t)seg_offsets[n_seg] * 1024 <= ((size_t)64 << 30)) {   // projections: 1 KiB per sample (a chunk stays < 4 GiB)
-            // H <= 64: project every sample once, then run the recurrences from the projections
+        } else if (c->lstm.NT == 8 && use_proj) {
+            // H <= 64: project every sample once, then run the recurrences from the projections (a chunk of P stays < 4 GiB)
             const long long n_samples = seg_offsets[n_seg];
-            const size_t pbytes = (size_t)n_samples * 8 * 32 * sizeof(float);
-            float* Pbuf = nullptr;
-            if ((rc = projections(pbytes, &Pbuf))) return rc;
             const size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);   // U + the flag row
             if (!c->rec_attr_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),

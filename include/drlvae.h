@@ -245,7 +245,10 @@ int drl_comm_destroy(drl_ctx* ctx);
 int drl_profile_enable(drl_ctx* ctx, int on);
 int drl_profile_reset(drl_ctx* ctx);
 int drl_profile_read(drl_ctx* ctx, int which, double* total_ms, int64_t* launches);
-/* Name of the LSTM kernel variant the last scoring call used ("h128i2" or "generic"). */
+/* Name of the LSTM kernel variant the last call used: "h128i2" (univariate, U stationary in registers),
+ * "h128i2_f16x3" (the same with drl_set_lstm_math 1), "xproj+rec" (any input width, hidden <= 64),
+ * "xproj+h128" (any input width, hidden 65..128), "gemv" (drl_q_predict on few states), "generic"
+ * (fallback: projections unavailable), "rollout_seq" (drl_rollout_batch's sequential kernel). */
 const char* drl_last_lstm_variant(drl_ctx* ctx);
 /* Windows per workgroup tile of that launch for the "h128i2" kernels (16, 32 or 64: chosen from the
  * size of the call; results are bit-identical across the three), 0 for the other variants. */

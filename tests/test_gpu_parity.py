@@ -422,6 +422,31 @@ def test_smd_series_normalised_in_float64(scorer):
     assert not np.array_equal(v32.view(np.uint32), v.view(np.uint32))
 
 
+def test_projection_buffer_unavailable_falls_back(scorer):
+    """When the per-sample projection buffer cannot be allocated the call still runs, on the fallback kernel."""
+    rng = np.random.default_rng(4)
+    F, N = 12, 500
+    x = rng.random((N, F), dtype=np.float32)
+    for H in (64, 128):
+        lstm = synth_lstm(rng, F + 1, H)
+        scorer.set_lstm(lstm)
+        kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", want=("q", "action"))
+        ref = scorer.score(x, W, **kw)
+        assert scorer.lstm_variant.startswith("xproj")
+        os.environ["DRLVAE_PBUF_MAX"] = "1024"
+        try:
+            got = scorer.score(x, W, **kw)
+        finally:
+            del os.environ["DRLVAE_PBUF_MAX"]
+        assert scorer.lstm_variant == "generic"
+        S = orc.states_multivariate(x, W, 0, N - W)
+        want = orc.lstm_q(S.reshape(-1, W, F + 1), lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0,
+                          dtype=np.float64).reshape(N - W, 2, 2)
+        for out in (ref, got):
+            rel = np.abs(out["q"].astype(np.float64) - want).reshape(N - W, -1).max(axis=1) / np.abs(want).reshape(N - W, -1).max(axis=1)
+            assert rel.max() <= RTOL
+
+
 def test_multivariate_h128_large_call_matches_small_calls(scorer):
     """Multivariate H = 128 (xproj + register-stationary recurrence): a large call runs 64-window
     tiles on a persistent grid, a small one 32-window tiles; same bits, and the small one is
