@@ -652,7 +652,8 @@ struct RecArgs {
                         // the refill is bound by L2/fabric throughput, not by latency
 #endif
 #ifndef REC_ABL
-#define REC_ABL 0     // timing-only ablations (wrong results): 1 no projection refill, 2 no cell update, 3 no flag term, 4 = 1+2
+#define REC_ABL 0     // timing-only ablations (wrong results): 1 no projection refill, 2 no cell update, 3 no flag term, 4 = 1+2,
+                      // 5 (rec2) no LDS reads of A fragments
 #endif
 template <int NT>
 __device__ __forceinline__ f32x16 rec_load_p(const char* __restrict__ P, size_t chunk_bytes, unsigned voff, int tl) {
@@ -810,8 +811,10 @@ __device__ __forceinline__ void rec_step2(f32x16 (&pq)[REC_RING], float (&aq)[2]
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
         f32x16 acc0 = pq[tl % REC_RING], acc1;
+#if REC_ABL != 1 && REC_ABL != 4
         pq[tl % REC_RING] = (tl + REC_RING < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + REC_RING)
                                    : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + REC_RING - NT);
+#endif
         {
             const f32x16 wf = load_bias16(s_fw, tl, half);
 #pragma unroll
@@ -821,8 +824,10 @@ __device__ __forceinline__ void rec_step2(f32x16 (&pq)[REC_RING], float (&aq)[2]
 #pragma unroll
             for (int g = 0; g < NT / 2; ++g) {
                 const int ng = (g + 1) % (NT / 2), ntl = (g + 1 < NT / 2) ? tl : (tl + 1) % NT;
+#if REC_ABL != 5
 #pragma unroll
                 for (int i = 0; i < 8; ++i) aq[(g + 1) & 1][i] = ul[((ng * 8 + i) * NT + ntl) * 64];
+#endif
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int kk = g * 8 + i;
@@ -834,8 +839,13 @@ __device__ __forceinline__ void rec_step2(f32x16 (&pq)[REC_RING], float (&aq)[2]
         }
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
+#if REC_ABL == 2 || REC_ABL == 4
+            hn[0][tl][qd] = (acc0[4 * qd] + acc0[4 * qd + 1]) + (acc0[4 * qd + 2] + acc0[4 * qd + 3]);
+            hn[1][tl][qd] = (acc1[4 * qd] + acc1[4 * qd + 1]) + (acc1[4 * qd + 2] + acc1[4 * qd + 3]);
+#else
             hn[0][tl][qd] = lstm_cell(acc0[4 * qd], acc0[4 * qd + 1], acc0[4 * qd + 2], acc0[4 * qd + 3], 0.0f, c[0][tl][qd]);
             hn[1][tl][qd] = lstm_cell(acc1[4 * qd], acc1[4 * qd + 1], acc1[4 * qd + 2], acc1[4 * qd + 3], 0.0f, c[1][tl][qd]);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     }

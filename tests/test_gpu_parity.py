@@ -919,6 +919,35 @@ def test_pipelined_host_call_equals_the_one_shot_call(scorer):
     assert one["q"].shape == (1, 2) and np.isfinite(out["q"][k_last]).all()
 
 
+def test_sharded_scoring_device_path_single_rank_rccl(scorer, a1, ckpt_a1):
+    """drlvae.dist.score_stream_sharded on its device-resident path — the shard scored by score_dev straight into
+    the rank's ScorePack, ONE all_gather_into_tensor over RCCL (backend "nccl"), no host round trip — with the
+    only communicator this one-GPU box can form (one rank).  The N = 2 form of the same code runs on CPU/gloo in
+    tests/test_host_logic.py and under bench.py's rehearsal in tests/test_gpu_bench.py."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from drlvae.dist import score_stream_sharded
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    v = a1["series"][5]
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        for mode in ("zeros", "quirk"):
+            got = score_stream_sharded(scorer, v, W, flag_mode=mode, device=dev)
+            want = scorer.score(v, W, flag_mode=mode)
+            for k in want:
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (mode, k)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_allgather_entry_point_single_rank():
     """drl_allgather_scores through the C-ABI with a one-rank communicator (the box has one GPU; RCCL
     refuses two ranks on one device): the gathered block must be the rank's own block."""
