@@ -1313,6 +1313,55 @@ template <int K>
 __device__ __forceinline__ float quad_bcast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
 }
+// z += h[16*m + N] * u with h[16*m + (lane & 15)] held in hreg by every row of 16 lanes: the broadcast
+// is the DPP operand of the multiply-add itself (row_newbcast: lane N of each row feeds the whole row),
+// so a unit costs one VALU instruction and no LDS traffic.  Reading h_t as broadcast ds_read_b128 made
+// the LDS return path the bound of a step (8 waves x 32 reads x 1 KiB: 2,048 cycles against 1,024 of
+// multiply-adds, measured 2,150).  v_fmac_f32 is the fused multiply-add fmaf is; the chain order is unchanged.
+// One asm statement per 16 units: between separate statements the compiler pads every DPP instruction
+// with an s_nop (it cannot see that the DPP operand is not the register just written).
+__device__ __forceinline__ float fmac_rowbcast16(float z, float hreg, const float* u) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(z)
+        : "v"(hreg), "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(u[4]), "v"(u[5]), "v"(u[6]), "v"(u[7]),
+          "v"(u[8]), "v"(u[9]), "v"(u[10]), "v"(u[11]), "v"(u[12]), "v"(u[13]), "v"(u[14]), "v"(u[15]));
+    return z;
+}
+// z += sum over units u = 0 .. HP-1 (ascending) of h[u] * U[u]; hs = h_t in LDS, [HP]
+template <int HP>
+__device__ __forceinline__ float gemv_chain(float z, const float (&U)[HP], const float* __restrict__ hs, int lane) {
+    float hreg[HP / 16];
+#pragma unroll
+    for (int m = 0; m < HP / 16; ++m) hreg[m] = hs[16 * m + (lane & 15)];
+#pragma unroll
+    for (int m = 0; m < HP / 16; ++m) z = fmac_rowbcast16(z, hreg[m], &U[16 * m]);
+    return z;
+}
+// lstm_cell for a quad of lanes that holds the four gate pre-activations of one unit (lane g: gate g of
+// i, j, f, o): every lane activates its own gate (one v_exp_f32 + one v_rcp_f32 instead of four of each)
+// and the quad exchanges the activated values.  Same operations on the same operands as lstm_cell
+// (fma(1, a, 0) == a for the sigmoid gates), so the same bits.
+__device__ __forceinline__ float lstm_cell_quad(float z, float act_mul, float act_add, float& c) {
+    const float v = fmaf(act_mul, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)), act_add);
+    const float si = quad_bcast<0>(v), tj = quad_bcast<1>(v), sf = quad_bcast<2>(v), so = quad_bcast<3>(v);
+    c = fmaf(sf, c, si * tj);
+    return so * fast_tanh(c);
+}
 template <int NT>
 __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
     constexpr int ROWS = 32 * NT, HP = 8 * NT;
@@ -1408,15 +1457,13 @@ __global__ __launch_bounds__(32 * NT, 1) void lstm_gemv_kernel(LstmArgs a) {
     __syncthreads();                                          // zx rows are read by other waves' threads
 
     float c = 0.0f;
+    const float act_mul = (i & 3) == 1 ? 2.0f : 1.0f, act_add = (i & 3) == 1 ? -1.0f : 0.0f;   // lane 1 of a quad: tanh
     for (int t = 0; t < W; ++t) {
         const float* __restrict__ hs = s_h[t & 1];
         float z = s_zx[t * ROWS + r];
-        if (t > 0) {
-#pragma unroll
-            for (int u = 0; u < HP; ++u) z = fmaf(U[u], hs[u], z);
-        }
+        if (t > 0) z = gemv_chain<HP>(z, U, hs, r);
         // the four gates of a unit sit in four consecutive lanes
-        const float hv = lstm_cell(quad_bcast<0>(z), quad_bcast<1>(z), quad_bcast<2>(z), quad_bcast<3>(z), a.forget_bias, c);
+        const float hv = lstm_cell_quad(z, act_mul, act_add, c);
         if ((i & 3) == 0) s_h[(t + 1) & 1][8 * tau + (i >> 2)] = hv;
         __syncthreads();
     }
@@ -1492,6 +1539,7 @@ __global__ __launch_bounds__(32 * NT, 1) void rollout_seq_kernel(RolloutSeqArgs 
     if (r < HP) { s_h[0][r] = 0.0f; s_h[1][r] = 0.0f; }
     __syncthreads();
 
+    const float act_mul = (i & 3) == 1 ? 2.0f : 1.0f, act_add = (i & 3) == 1 ? -1.0f : 0.0f;   // lane 1 of a quad: tanh
     for (long long k = 0; k < K; ++k) {
         // the sample that enters the window at the next cursor: requested now, used after the action is known
         const float v_next = k + 1 < K ? value(k + W + 1) : 0.0f;
@@ -1501,11 +1549,8 @@ __global__ __launch_bounds__(32 * NT, 1) void rollout_seq_kernel(RolloutSeqArgs 
             const float* __restrict__ hs = s_h[t & 1];
             float z = rs_zx[slot * ROWS + r];
             slot = slot + 1 == W ? 0 : slot + 1;
-            if (t > 0) {
-#pragma unroll
-                for (int u = 0; u < HP; ++u) z = fmaf(U[u], hs[u], z);
-            }
-            const float hv = lstm_cell(quad_bcast<0>(z), quad_bcast<1>(z), quad_bcast<2>(z), quad_bcast<3>(z), a.forget_bias, c);
+            if (t > 0) z = gemv_chain<HP>(z, U, hs, r);
+            const float hv = lstm_cell_quad(z, act_mul, act_add, c);
             if ((i & 3) == 0) s_h[(t + 1) & 1][8 * tau + (i >> 2)] = hv;
             __syncthreads();
         }

@@ -5,6 +5,28 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define N_ITER 4096
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 (v_pk_fma_f32: two fmas per lane per instruction) next to the MFMA stream
+template <int PK_PER_MFMA>
+__global__ __launch_bounds__(256, 1) void k_same_wave_pk(float* out, float a, float b) {
+    f32x16 acc[4] = {};
+    f32x2 v[8];
+    for (int i = 0; i < 8; ++i) v[i] = f32x2{a + i + threadIdx.x, b + i};
+    const f32x2 a2 = {a, a}, b2 = {b, b};
+    for (int it = 0; it < N_ITER; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < PK_PER_MFMA; ++q) v[q & 7] = __builtin_elementwise_fma(v[q & 7], a2, b2);
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i].x + v[i].y;
+    for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += acc[m][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int VALU_PER_MFMA, bool TRANS>
 __global__ __launch_bounds__(256, 1) void k_same_wave(float* out, float a, float b) {
     f32x16 acc[4] = {};
@@ -71,6 +93,8 @@ int main() {
     RUN("same wave, 8 fma/mfma", (k_same_wave<8, false>), 256);
     RUN("same wave, 12 fma/mfma", (k_same_wave<12, false>), 256);
     RUN("same wave, 4 exp/mfma", (k_same_wave<4, true>), 256);
+    RUN("same wave, 4 pk_fma/mfma", (k_same_wave_pk<4>), 256);
+    RUN("same wave, 8 pk_fma/mfma", (k_same_wave_pk<8>), 256);
     RUN("two waves, 4 fma/mfma", (k_two_waves<4, false>), 512);
     RUN("two waves, 8 fma/mfma", (k_two_waves<8, false>), 512);
     RUN("two waves, 12 fma/mfma", (k_two_waves<12, false>), 512);
