@@ -1283,6 +1283,13 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     if ((rc = ensure(c, c->st_in, (size_t)total * F * sizeof(float)))) return rc;
     const bool explicit_flags = o->flag_mode == DRL_FLAG_EXPLICIT;
     if (explicit_flags && (rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
+    // an error return after the first asynchronous copy waits for the copies still reading the caller's
+    // buffers (a pinned host buffer is read by the DMA engine after hipMemcpyAsync has returned)
+    auto drain = [&](int code) {
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+        return code;
+    };
     const float* d_eps = nullptr;
     if (o->eps && recon_err) {
         if (!c->vae.set) return fail(c, DRL_ERR_STATE, "eps given but drl_set_vae was not called");
@@ -1291,10 +1298,10 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
         HIP_TRY(c, hipMemcpyAsync(c->st_eps.p, o->eps, n, hipMemcpyHostToDevice, c->stream));
         d_eps = (const float*)c->st_eps.p;
     }
-    if (recon_err && (rc = ensure(c, c->st_err, (size_t)K * sizeof(float)))) return rc;
-    if (want_q && (rc = ensure(c, c->st_q, (size_t)K * S * A * sizeof(float)))) return rc;
-    if (action && (rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t)))) return rc;
-    if (margin && (rc = ensure(c, c->st_margin, (size_t)K * sizeof(float)))) return rc;
+    if (recon_err && (rc = ensure(c, c->st_err, (size_t)K * sizeof(float)))) return drain(rc);
+    if (want_q && (rc = ensure(c, c->st_q, (size_t)K * S * A * sizeof(float)))) return drain(rc);
+    if (action && (rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t)))) return drain(rc);
+    if (margin && (rc = ensure(c, c->st_margin, (size_t)K * sizeof(float)))) return drain(rc);
     float* const d_in = (float*)c->st_in.p;
     float* const d_fl = explicit_flags ? (float*)c->st_flags.p : nullptr;
 
@@ -1314,10 +1321,10 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
         rc = score_impl(c, d_in, seg_offsets, n_seg, F, W, o, d_fl, d_eps,
                         recon_err ? (float*)c->st_err.p : nullptr, want_q ? (float*)c->st_q.p : nullptr,
                         action ? (int32_t*)c->st_act.p : nullptr, margin ? (float*)c->st_margin.p : nullptr, nullptr);
-        if (rc) return rc;
+        if (rc) return drain(rc);
     } else {
         OptDev od_all;                                   // one upload of the option tables for every chunk
-        if ((rc = upload_opts(c, o, n_seg, W * F, od_all))) return rc;
+        if ((rc = upload_opts(c, o, n_seg, W * F, od_all))) return drain(rc);
         HIP_TRY(c, hipStreamSynchronize(c->stream));      // st_in may still be read by an earlier asynchronous call
         // Chunk sizes grow: a first chunk of 8 MB puts the GPU to work after a third of a millisecond, the later
         // ones are large enough to fill the chip (1,024 waves of 32 windows) — a call costs the
@@ -1381,13 +1388,14 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
                                 want_q ? (float*)c->st_q.p + (size_t)win_done * S * A : nullptr,
                                 action ? (int32_t*)c->st_act.p + win_done : nullptr,
                                 margin ? (float*)c->st_margin.p + win_done : nullptr, nullptr, false, &od);
-                if (rc) return rc;
+                if (rc) return drain(rc);
                 win_done += kwin;
             }
             ++n_chunk;
             chunk_samples = std::min(chunk_samples * 2, chunk_cap);
         }
-        if (win_done != K) return fail(c, DRL_ERR_STATE, "drl_score_batch: the chunk plan covered %lld of %lld windows", win_done, K);
+        if (win_done != K)
+            return drain(fail(c, DRL_ERR_STATE, "drl_score_batch: the chunk plan covered %lld of %lld windows", win_done, K));
     }
     if (recon_err) HIP_TRY(c, hipMemcpyAsync(recon_err, c->st_err.p, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (q) HIP_TRY(c, hipMemcpyAsync(q, c->st_q.p, (size_t)K * S * A * sizeof(float), hipMemcpyDeviceToHost, c->stream));
