@@ -106,6 +106,8 @@ struct drl_ctx {
     int rollout_mode = 0;         // drl_rollout_batch: 0 auto, 1 fixed-point over full-parallel passes, 2 one persistent
                                   // workgroup per series (DRLVAE_ROLLOUT / drl_set_rollout_mode)
     size_t rollout_lds_set = 0;
+    const int* tl_dev = nullptr;  // set by drl_rollout_batch around a sparse pass: the 16-window tiles score_impl works on
+    int tl_n = 0;
     int rec2_mode = 1;            // two candidate states in one wave: 0 never, 1 whole rounds of tiles, 2 always (DRLVAE_REC2)
     bool last_overlap = false;
     std::string err;
@@ -1096,7 +1098,18 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         }
         c->last_tile = 0;
         if (prof) prof_begin(c, 0, c->stream);
-        if (fast && c->lstm_math == 1 && c->lstm.has_split) {
+        if (fast && c->tl_n > 0 && c->lstm.has16) {
+            // a sparse pass of the rollout's fixed point: only the listed 16-window tiles
+            a.seg.tile_off = sh.d_t16; a.n_tiles = c->tl_n; a.tile_list = c->tl_dev;
+            Lstm16Args fa;
+            fa.l = a;
+            fa.u16 = (const float*)c->lstm_w.p + c->lstm.u16_off;
+            fa.wx16 = (const float*)c->lstm_w.p + c->lstm.wx16_off;
+            fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
+            // more tiles than CUs: a workgroup walks several (the recurrent weights are loaded once)
+            hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(std::min(c->tl_n, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
+            c->last_variant = "h128i2"; c->last_tile = 16;
+        } else if (fast && c->lstm_math == 1 && c->lstm.has_split) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             LstmF16Args fa;
             fa.l = a;
@@ -1636,15 +1649,15 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
     if ((rc = ensure(c, c->st_flags, (size_t)total * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->st_q, (size_t)K * A * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->st_act, (size_t)K * sizeof(int32_t) + 64))) return rc;
-    if ((rc = ensure(c, c->st_margin, 256))) return rc;             // the "changed" word
     HIP_TRY(c, hipMemcpyAsync(c->st_in.p, series, (size_t)total * sizeof(float), hipMemcpyHostToDevice, c->stream));
     // Two exact designs (measured: tools/rollout_time.py -> profiles/r2/rollout_time.txt):
-    //  * fixed point over full-parallel scoring passes: as many passes as the busiest series has runs of
-    //    action changes (+1), each as long as one scoring call of the whole batch (0.15 ms for one Yahoo
-    //    series, 2.4 ms for all 67) — 8 to 90 times faster than stepping on the validation sets;
+    //  * fixed point over parallel scoring passes: as many passes as the busiest series has runs of action
+    //    changes (+1); the first scores every window (0.15 ms for one Yahoo series, 2.5 ms for all 67), the
+    //    later ones only the tiles a changed flag reaches (0.13-0.3 ms): 0.4-1.8 ms on the validation sets,
+    //    9.7 ms for all 67 A1 series (33 passes; 81 ms with full passes only);
     //  * sequential kernel: one persistent workgroup per series, W dependent matrix-vector steps per cursor
-    //    (22.5 us at W = 25), whatever the actions are, series in parallel one per CU: 32 ms for any batch of
-    //    Yahoo-length series — 2.5 times faster than the fixed point on all 67 A1 series (33 passes).
+    //    (19.8 us at W = 25), whatever the actions are, series in parallel one per CU: 28 ms for any batch of
+    //    Yahoo-length series.
     // Auto starts with the fixed point and hands over to the sequential kernel once the passes made have cost
     // what the sequential kernel would (its time is known in advance): never more than twice the better one.
     long long longest = 0;
@@ -1655,7 +1668,7 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
         return fail(c, DRL_ERR_UNSUPPORTED, "drl_rollout_batch: the sequential kernel holds W*%d floats in LDS (W = %d is too long)", 32 * c->lstm.NT, W);
     const double seq_est_us = (double)longest * W * 0.9;
     const double pass_est_us = std::max(150.0, (double)K * W * (c->lstm.NT == 16 ? 0.00105 : 0.0006));
-    const int pass_budget = (c->rollout_mode == 0 && seq_ok) ? (int)std::max(2.0, seq_est_us / pass_est_us) : 0x7fffffff;
+    const bool may_hand_over = c->rollout_mode == 0 && seq_ok;
     auto run_sequential = [&]() -> int {
         SegHost sh;
         if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
@@ -1698,31 +1711,53 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
     o.in_scale = in_scale; o.in_offset = in_offset;
     SegHost sh;
     if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
+    // Sparse passes: a flag that changed in a pass alters only the W windows that hold its sample, so the next
+    // pass scores the 16-window tiles of those windows and nothing else (the others keep their Q: exactly what a
+    // full pass would write again).  The number of passes is that of the full iteration; from the second on a
+    // pass costs one latency-bound launch over a few tiles instead of a scoring call of the whole batch (all 67
+    // A1 series: 33 passes, 81 -> 9 ms).  Needs the register-stationary fp32 kernel family (16-window tiles).
+    const bool sparse_ok = c->lstm.I == 2 && c->lstm.NT == 16 && c->lstm.has16 && c->lstm_math == 0 &&
+                           W + 65 <= H128_SV && getenv("DRLVAE_ROLLOUT_DENSE") == nullptr;
+    const size_t ctl_bytes = 256;                                      // ctl[0] = changed, ctl[1] = tiles listed
+    if ((rc = ensure(c, c->st_margin, ctl_bytes + (sparse_ok ? (size_t)2 * sh.tiles16 * sizeof(int) : 0)))) return rc;
     SegTab seg;
     memset(&seg, 0, sizeof seg);
-    seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t32; seg.n_seg = n_seg; seg.W = W;
+    seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t16; seg.n_seg = n_seg; seg.W = W;
     float* d_flags = (float*)c->st_flags.p;
-    int* d_changed = (int*)c->st_margin.p;
+    int* d_ctl = (int*)c->st_margin.p;
+    int* d_dirty = sparse_ok ? (int*)((char*)c->st_margin.p + ctl_bytes) : nullptr;
+    int* d_list = sparse_ok ? d_dirty + sh.tiles16 : nullptr;
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, d_flags, seg, total);
     hipLaunchKernelGGL(rollout_init1_kernel, dim3((n_seg + 63) / 64), dim3(64), 0, c->stream, d_flags, seg);
     HIP_TRY(c, hipGetLastError());
-    int passes = 0;
+    int passes = 0, listed = 0;
+    double spent_us = 0.0;
     long long max_K = 0;
     for (int i = 0; i < n_seg; ++i) max_K = std::max<long long>(max_K, seg_offsets[i + 1] - seg_offsets[i] - W);
     for (;;) {
+        // a listed tile costs a workgroup W steps of ~5 us; when the rounds of such workgroups add up to most of
+        // a full pass (persistent 64-window tiles, the more efficient mapping), the full pass it is
+        const double sparse_us = 30.0 + (double)((listed + c->n_cu - 1) / c->n_cu) * W * 5.0;
+        const bool sparse = sparse_ok && listed > 0 && sparse_us < 0.8 * pass_est_us;
+        c->tl_dev = sparse ? d_list : nullptr;
+        c->tl_n = sparse ? listed : 0;
         rc = score_impl(c, (const float*)c->st_in.p, seg_offsets, n_seg, 1, W, &o, d_flags, nullptr,
                         nullptr, (float*)c->st_q.p, (int32_t*)c->st_act.p, nullptr, nullptr);
+        c->tl_dev = nullptr; c->tl_n = 0;
         if (rc) return rc;
         ++passes;
-        HIP_TRY(c, hipMemsetAsync(d_changed, 0, sizeof(int), c->stream));
+        spent_us += sparse ? sparse_us : pass_est_us;
+        HIP_TRY(c, hipMemsetAsync(d_ctl, 0, 2 * sizeof(int), c->stream));
+        if (d_dirty) HIP_TRY(c, hipMemsetAsync(d_dirty, 0, (size_t)sh.tiles16 * sizeof(int), c->stream));
         hipLaunchKernelGGL(rollout_feedback_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c->stream,
-                           (const int*)c->st_act.p, d_flags, seg, K, d_changed);
+                           (const int*)c->st_act.p, d_flags, seg, K, d_ctl, d_dirty, d_list);
         HIP_TRY(c, hipGetLastError());
-        int changed = 0;
-        HIP_TRY(c, hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int ctl[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (!changed) break;
-        if (passes >= pass_budget) {
+        if (!ctl[0]) break;
+        listed = ctl[1];
+        if (may_hand_over && spent_us >= seq_est_us) {
             // auto: the passes so far have cost what stepping through the series costs — finish that way
             if (passes_out) *passes_out = passes;
             return run_sequential();

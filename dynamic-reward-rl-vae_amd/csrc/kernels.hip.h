@@ -452,6 +452,7 @@ struct LstmArgs {
     int n_tiles;
     int S;                  // candidate states per window (gridDim.y)
     float* q;               // [K_total, S, A]
+    const int* tile_list;   // null, or the n_tiles tile indices to work on (the sparse passes of drl_rollout_batch)
 };
 
 __device__ __forceinline__ float synth_flag(int mode, long long k, int t, int W, int cand,
@@ -1615,8 +1616,13 @@ __global__ void finalize_kernel(const float* __restrict__ q, long long K, int S,
 // sequential rollout, after (number of action changes + 1) full-parallel passes.
 //
 // One thread per window: writes flag[sample of cursor k+W+1] = action[k] and reports a change.
+// A changed flag alters the states of the W windows that hold its sample and of no others, so the next pass
+// needs only those: when `dirty` is given, their 16-window tiles (seg.tile_off = the 16-window tile table) are
+// appended, once each, to `list` (ctl[0] = changed, ctl[1] = tiles in the list).  The windows outside the list
+// keep the Q they have, which is what a full pass would compute again.
 __global__ void rollout_feedback_kernel(const int* __restrict__ action, float* __restrict__ flags,
-                                        SegTab seg, long long K_total, int* __restrict__ changed) {
+                                        SegTab seg, long long K_total, int* __restrict__ ctl,
+                                        int* __restrict__ dirty, int* __restrict__ list) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= K_total) return;
     int lo = 0, hi = seg.n_seg;
@@ -1626,7 +1632,18 @@ __global__ void rollout_feedback_kernel(const int* __restrict__ action, float* _
     if (k + 1 >= Ks) return;                               // the last action feeds no later state
     const long long n = seg.samp_off[lo] + seg.W + 1 + k;
     const float nf = (float)action[g];
-    if (flags[n] != nf) { flags[n] = nf; *changed = 1; }
+    if (flags[n] != nf) {
+        flags[n] = nf;
+        ctl[0] = 1;
+        if (dirty) {
+            // sample W+1+k of the series is row t of window k' = k+1+(W-1-t): k' = k+1 .. k+W
+            const long long k_hi = k + seg.W < Ks - 1 ? k + seg.W : Ks - 1;
+            for (long long t16 = (k + 1) >> 4; t16 <= (k_hi >> 4); ++t16) {
+                const int tile = seg.tile_off[lo] + (int)t16;
+                if (atomicExch(&dirty[tile], 1) == 0) list[atomicAdd(&ctl[1], 1)] = tile;
+            }
+        }
+    }
 }
 // initial state: flags 0 except the 1 the first state carries in its last row (myasp-A1.py:126)
 __global__ void rollout_init_kernel(float* __restrict__ flags, SegTab seg, long long n_total) {

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) 
     const float fb = a.forget_bias;
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int ti = blockIdx.x; ti < a.n_tiles; ti += gridDim.x) {
+        const int tile = a.tile_list ? a.tile_list[ti] : ti;
         const SegHit sg = seg_lookup(s_seg, a.seg, tile);
         const int s = sg.s;
         const long long samp0 = sg.samp0, nsamp = sg.nsamp;

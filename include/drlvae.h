@@ -188,7 +188,8 @@ int drl_q_predict(drl_ctx* ctx, const float* states, int64_t B, int W, float* q)
  * env.step, env.py:82-94, 126-151) for univariate series: start from the initial state (flags
  * [0]*(W-1)+[1]), act greedily (np.argmax, ties -> 0), feed each action back as the flag of the
  * next sample.  Computed as a fixed-point iteration over full-parallel teacher-forced passes
- * (exactly the sequential result; see rollout_feedback_kernel).  Host pointers, synchronous.
+ * (exactly the sequential result; see rollout_feedback_kernel); from the second pass on only the
+ * windows that hold a sample whose flag changed are scored again.  Host pointers, synchronous.
  *   action [K_total] (required), q [K_total, A] (optional) = Q of the state the policy saw at each
  *   cursor; passes_out (optional) = number of parallel passes it took.
  * in_scale/in_offset: optional per-series MinMax parameters as in drl_score_opts. */
@@ -196,11 +197,12 @@ int drl_rollout_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offs
                       const float* in_scale, const float* in_offset,
                       int32_t* action, float* q, int32_t* passes_out);
 /* Which of the two exact designs drl_rollout_batch runs (no counterpart in the reference):
- *   1  the fixed point over full-parallel scoring passes described above (passes_out = their number);
+ *   1  the fixed point over parallel scoring passes described above (passes_out = their number);
  *   2  one persistent workgroup per series that steps through the cursors, the action written straight
  *      into the next state's flag (passes_out = 0); series run in parallel, one per CU;
  *   0  (default) starts as 1 and hands over to 2 once the passes made have cost what 2 would (known in
- *      advance: 0.9 us per cursor and time step of the longest series): at most twice the better of the two.
+ *      advance: 0.9 us per cursor and time step of the longest series; the passes are priced by the tiles
+ *      they score): at most twice the better of the two.
  *      passes_out = the passes made before the hand-over.
  * Both give the sequential rollout's actions and the same Q, bit for bit.  Environment: DRLVAE_ROLLOUT. */
 int drl_set_rollout_mode(drl_ctx* ctx, int mode);

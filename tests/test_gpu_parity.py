@@ -702,15 +702,34 @@ def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckp
         assert len(got_a) == 80 + 1 + 350 and np.array_equal(got_a, want_a)
         assert np.array_equal(got_q.view(np.uint32), want_q.view(np.uint32))
         assert np.array_equal(got_a[:80], orc.rollout_greedy(v[:130], 50, l64["kernel"], l64["bias"], l64["w_out"], l64["b_out"]))
-        # auto on all 67 A1 series (33 passes of 2.4 ms against 32 ms of stepping): hands over after its budget
+        # all 67 A1 series, 1,920 alarms, 33 passes.  From the second pass on the fixed point scores only the
+        # 16-window tiles that a changed flag reaches: same passes, same actions, same Q bits as with full passes
+        # (DRLVAE_ROLLOUT_DENSE=1) and as the sequential kernel
         scorer.set_lstm(lstm)
-        scorer.set_rollout_mode("auto")
         flat = np.concatenate(a1["series"])
         offs = np.concatenate([[0], np.cumsum([len(v) for v in a1["series"]])])
-        auto = scorer.rollout(flat, W, offs)
-        handed_over = scorer.lstm_variant == "rollout_seq"
+        scorer.set_rollout_mode("fixed_point")
+        sparse_a, sparse_q = scorer.rollout(flat, W, offs, return_q=True)
+        sparse_passes = scorer.last_rollout_passes
+        os.environ["DRLVAE_ROLLOUT_DENSE"] = "1"
+        try:
+            dense_a, dense_q = scorer.rollout(flat, W, offs, return_q=True)
+            assert scorer.last_rollout_passes == sparse_passes == 33
+            # auto with full passes only (33 of 2.4 ms against 28 ms of stepping): hands over after its budget
+            scorer.set_rollout_mode("auto")
+            auto = scorer.rollout(flat, W, offs)
+            assert scorer.lstm_variant == "rollout_seq" and 0 < scorer.last_rollout_passes < 33
+        finally:
+            del os.environ["DRLVAE_ROLLOUT_DENSE"]
+        assert np.array_equal(sparse_a, dense_a) and np.array_equal(sparse_q.view(np.uint32), dense_q.view(np.uint32))
+        assert np.array_equal(auto, dense_a) and int(auto.sum()) == 1920
         scorer.set_rollout_mode("sequential")
-        assert np.array_equal(auto, scorer.rollout(flat, W, offs)) and handed_over and int(auto.sum()) == 1920
+        seq_a, seq_q = scorer.rollout(flat, W, offs, return_q=True)
+        assert np.array_equal(seq_a, sparse_a) and np.array_equal(seq_q.view(np.uint32), sparse_q.view(np.uint32))
+        # auto with sparse passes: the fixed point finishes inside its budget
+        scorer.set_rollout_mode("auto")
+        assert np.array_equal(scorer.rollout(flat, W, offs), sparse_a)
+        assert scorer.lstm_variant != "rollout_seq" and scorer.last_rollout_passes == 33
     finally:
         scorer.set_rollout_mode("auto")
         scorer.set_lstm(lstm)

@@ -14,19 +14,23 @@ sc = WindowScorer(0)
 
 def timed(values, offsets, label):
     res = {}
-    for mode in ("fixed_point", "sequential", "auto"):
-        sc.set_rollout_mode(mode)
+    for mode in ("fixed_point_full_passes", "fixed_point", "sequential", "auto"):
+        sc.set_rollout_mode("fixed_point" if mode.startswith("fixed") else mode)
+        if mode == "fixed_point_full_passes":
+            os.environ["DRLVAE_ROLLOUT_DENSE"] = "1"
         for _ in range(2):
             sc.rollout(values, W, offsets)
         t0 = time.perf_counter()
         for _ in range(5):
             a = sc.rollout(values, W, offsets)
         res[mode] = ((time.perf_counter() - t0) / 5, a, sc.last_rollout_passes)
+        os.environ.pop("DRLVAE_ROLLOUT_DENSE", None)
     (tf, af, pf), (ts, as_, _), (ta, aa, pa) = res["fixed_point"], res["sequential"], res["auto"]
-    assert np.array_equal(af, as_) and np.array_equal(af, aa)
+    td, ad, pd_ = res["fixed_point_full_passes"]
+    assert np.array_equal(af, as_) and np.array_equal(af, aa) and np.array_equal(af, ad) and pd_ == pf
     n = 1 if offsets is None else len(offsets) - 1
     print(f"{label}: {n} series, {len(af)} cursors, {int(af.sum())} alarms | fixed point {pf} passes {tf * 1e3:.2f} ms "
-          f"({tf / pf * 1e6:.0f} us per pass) | sequential kernel {ts * 1e3:.2f} ms ({ts / max(1, len(af) if n == 1 else max(np.diff(offsets)) - W) * 1e6:.1f} us per cursor of the longest series)"
+          f"({tf / pf * 1e6:.0f} us per pass; with full passes only {td * 1e3:.2f} ms) | sequential kernel {ts * 1e3:.2f} ms ({ts / max(1, len(af) if n == 1 else max(np.diff(offsets)) - W) * 1e6:.1f} us per cursor of the longest series)"
           f" | faster: {'sequential' if ts < tf else 'fixed point'} x{max(tf, ts) / min(tf, ts):.1f}"
           f" | auto {ta * 1e3:.2f} ms ({pa} passes{', then the sequential kernel' if sc.lstm_variant == 'rollout_seq' else ''})")
 
