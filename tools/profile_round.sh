@@ -10,6 +10,9 @@ for spec in "c1 300 20" "c3 40 5" "c4 8 2" "c5 5 2"; do
   set -- $spec
   timeout -k 10 300 python -u bench.py --workload $1 --steps $2 --warmup $3 --no-cpu-baseline > $out/bench_$1.json 2> $out/bench_$1.err
 done
+# the n_hidden_dim = 128 variants of the multivariate configurations (C3 "H128")
+timeout -k 10 300 python -u bench.py --workload c3 --hidden 128 --steps 40 --warmup 5 --no-cpu-baseline > $out/bench_c3_h128.json 2> $out/bench_c3_h128.err
+timeout -k 10 300 python -u bench.py --workload c4 --hidden 128 --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_c4_h128.json 2> $out/bench_c4_h128.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --no-cpu-baseline --no-alt > $out/trace_c2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c4 -- python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c4.log 2>&1
 # PMC passes, one counter group per run (a run may hold at most 8 SQ / 4 TCC counters): C2 and C4
@@ -23,6 +26,6 @@ done
 for f in $out/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]
-print(sys.argv[1].split("_")[-1][:2], f"{d['value']/1e6:.2f} Mwin/s", f"lstm {r['avg_launch_ms']:.3f} ms frac {r['frac']:.3f}", f"vae {r['vae_kernel_avg_ms']:.3f} ms", d["config"]["lstm_kernel"], d.get("cpu_baseline",{}).get("value"))
+print(sys.argv[1].split("bench_")[-1][:-5], f"{d['value']/1e6:.2f} Mwin/s", f"lstm {r['avg_launch_ms']:.3f} ms frac {r['frac']:.3f}", f"vae {r['vae_kernel_avg_ms']:.3f} ms", d["config"]["lstm_kernel"], d.get("cpu_baseline",{}).get("value"))
 PY
 done
