@@ -462,7 +462,18 @@ int drl_create(int device_id, drl_ctx** out) {
         return fail(nullptr, DRL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+    // the second stream carries the VAE kernel beside the LSTM kernels; DRLVAE_AUX_PRIO=low|high creates it
+    // at the lowest / highest stream priority (measurement knob; default: the same priority as the main stream)
+    hipError_t aux_e;
+    {
+        const char* pe = getenv("DRLVAE_AUX_PRIO");
+        int least = 0, greatest = 0;
+        if (pe && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+            aux_e = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, pe[0] == 'h' ? greatest : least);
+        else
+            aux_e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    }
+    if (aux_e != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
@@ -1058,11 +1069,13 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         HIP_TRY(c, hipGetLastError());
         return DRL_OK;
     };
-    // Worth it when the VAE is a real GEMM (wide windows) and the call is large — measured +7 % on C4
-    // (172,776 windows, D = 3075), +1 % on C2, -2 % on C3 (28,454 windows: the fork/join costs more than
-    // the tail it fills) — and when the call is so small that the LSTM grid leaves CUs idle anyway
-    // (C1, 1,395 windows: +13 %).  DRLVAE_OVERLAP=0 turns it off, =2 forces it for every call.
-    const bool big_wide = W * F > 128 && sh.K_total >= 65536;
+    // Worth it when the call is large — measured (round 2) +3 % on C4 (172,776 windows, D = 3075), +2 % on C2
+    // (93,191 windows: the 0.05 ms of the chain VAE kernel disappear under the LSTM kernel's last round),
+    // +0.3 % on C5, but -3 % on C3 (28,454 windows: the LSTM grid is a single round that wants every CU
+    // at once) — and when the call is so small that the LSTM grid leaves CUs idle anyway (C1, 1,395
+    // windows: +13 %).  The second stream's priority makes no difference (DRLVAE_AUX_PRIO, tools/ab_prio.sh).
+    // DRLVAE_OVERLAP=0 turns it off, =2 forces it for every call.
+    const bool big_wide = sh.K_total >= 65536;
     const bool small = (long long)sh.tiles32 * (o->flag_mode == DRL_FLAG_BOTH ? 2 : 1) <= (long long)c->n_cu * 3 / 4;
     const bool overlap = want_vae && want_q && c->aux_stream &&
                          (c->overlap_mode == 2 || (c->overlap_mode == 1 && (big_wide || small)));
