@@ -1176,14 +1176,15 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         } else if (c->lstm.NT == 8 && use_proj) {
             // H <= 64: project every sample once, then run the recurrences from the projections (a chunk of P stays < 4 GiB)
             const long long n_samples = seg_offsets[n_seg];
-            const size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);   // U + the flag row
+            size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);   // U + the flag row
+            if (const char* e = getenv("DRLVAE_REC_LDS_PAD")) lds = std::min<size_t>(lds + (size_t)atoi(e), 160 * 1024);   // measurement knob: workgroups per CU
             if (!c->rec_attr_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec2_kernel<8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 c->rec_attr_set = true;
             }
             XprojArgs xa;
@@ -1609,11 +1610,11 @@ int drl_q_predict(drl_ctx* c, const float* states, int64_t B, int W, float* q) {
             const size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);
             if (!c->rec_attr_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec2_kernel<8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 c->rec_attr_set = true;
             }
             ra.l = a;
