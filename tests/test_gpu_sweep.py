@@ -11,6 +11,10 @@ from oracle import ref_path as orc
 from test_gpu_parity import RTOL, synth_lstm, synth_vae
 
 pytestmark = pytest.mark.gpu
+# DRLVAE_SWEEP_SEEDS=N widens the two randomised sweeps to N seeds each (a one-off soak run; the default is what
+# the suite runs every time)
+N_UNI = int(os.environ.get("DRLVAE_SWEEP_SEEDS", 16))
+N_MULTI = int(os.environ.get("DRLVAE_SWEEP_SEEDS", 12))
 
 
 @pytest.fixture(scope="module")
@@ -28,6 +32,25 @@ def _nrel(got, want):
     return (np.abs(got - want).max(axis=1) / np.maximum(np.abs(want).max(axis=1), 1e-30)).max() if len(want) else 0.0
 
 
+SOAK = "DRLVAE_SWEEP_SEEDS" in os.environ
+
+
+def _q_tol(q32, q64):
+    """The bar for Q against the fp64 oracle is 1e-5 of the window's largest |Q| (north_star), and that is what the
+    suite's fixed seeds are held to.  The soak run (DRLVAE_SWEEP_SEEDS=300) meets, about once in 150 random
+    networks, one whose Q head cancels to a few percent of its terms; float32 arithmetic itself cannot hold the
+    bar there — the oracle's own float32 run is off its float64 run by 3e-6 .. 7e-6 on those — so the soak run
+    allows eight times the oracle's float32 deviation where that is the larger bound."""
+    return max(RTOL, 8.0 * _nrel(q32, q64)) if SOAK else RTOL
+
+
+def _err_atol(err32, err64):
+    """Same for the reconstruction error: a window that the VAE reconstructs almost exactly (err 1e-6 where the
+    batch's typical error is 1e-2) is a difference of nearly equal numbers.  Soak run only: absolute slack of
+    eight times the float32 oracle's largest deviation in the batch."""
+    return 8.0 * float(np.abs(np.asarray(err32, np.float64) - err64).max()) if SOAK and len(err64) else 0.0
+
+
 def _rand_vae(rng, D):
     n_enc = int(rng.integers(1, 4))
     hid = [int(rng.choice([8, 33, 64, 100, 128])) for _ in range(n_enc)]
@@ -36,7 +59,7 @@ def _rand_vae(rng, D):
     return synth_vae(rng, [D] + hid + [lat, dec, D], n_enc), hid, dec
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(N_UNI))
 def test_univariate_random_shapes(scorer, seed):
     rng = np.random.default_rng(1000 + seed)
     Wn = int(rng.integers(2, 61))
@@ -79,6 +102,8 @@ def test_univariate_random_shapes(scorer, seed):
         rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
                               10.0, dtype=np.float64)
         err = orc.recon_error(X, rec, dtype=np.float64)
+        err32 = orc.recon_error(X, orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"],
+                                                   vae["logvar_layer"], 10.0, dtype=np.float32), dtype=np.float32)
         S = orc.states_list_univariate(v, Wn)
         if mode == "zeros":
             S[:, :, 1] = 0
@@ -87,8 +112,9 @@ def test_univariate_random_shapes(scorer, seed):
             idx = np.arange(k)[:, None] + 1 + np.arange(Wn)[None, :]
             S[:, :, 1] = fl[idx]
         q = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float64)
-        np.testing.assert_allclose(out["err"][pos:pos + k], err, rtol=RTOL, err_msg=f"W={Wn} H={H}")
-        assert _nrel(out["q"][pos:pos + k], q) <= RTOL, (Wn, H, A, mode, device_minmax, scorer.lstm_variant)
+        q32 = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float32)
+        np.testing.assert_allclose(out["err"][pos:pos + k], err, rtol=RTOL, atol=_err_atol(err32, err), err_msg=f"W={Wn} H={H}")
+        assert _nrel(out["q"][pos:pos + k], q) <= _q_tol(q32, q), (Wn, H, A, mode, device_minmax, scorer.lstm_variant)
         srt = np.sort(q, axis=1)
         safe = (srt[:, -1] - srt[:, -2]) > 4 * RTOL * np.abs(q).max(axis=1)
         assert np.array_equal(out["action"][pos:pos + k][safe], np.argmax(q, axis=1)[safe])
@@ -98,7 +124,7 @@ def test_univariate_random_shapes(scorer, seed):
     assert pos == K
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_MULTI))
 def test_multivariate_random_shapes(scorer, seed):
     rng = np.random.default_rng(2000 + seed)
     Wn = int(rng.integers(3, 31))
@@ -136,9 +162,10 @@ def test_multivariate_random_shapes(scorer, seed):
         if k == 0:
             continue
         want = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float64)
-        np.testing.assert_allclose(out["err"][pos:pos + k], want["err"], rtol=RTOL,
+        want32 = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float32)
+        np.testing.assert_allclose(out["err"][pos:pos + k], want["err"], rtol=RTOL, atol=_err_atol(want32["err"], want["err"]),
                                    err_msg=f"W={Wn} F={F} hid={hid} dec={dec} {scorer._lib.drl_last_lstm_variant(scorer._h)}")
-        assert _nrel(out["q"][pos:pos + k], want["q"]) <= RTOL, (Wn, F, H, scorer.lstm_variant)
+        assert _nrel(out["q"][pos:pos + k], want["q"]) <= _q_tol(want32["q"], want["q"]), (Wn, F, H, scorer.lstm_variant)
         m = np.abs(want["q"][:, 1, 1] - want["q"][:, 0, 0])
         safe = m > 4 * RTOL * np.abs(want["q"]).max(axis=(1, 2))
         assert np.array_equal(out["action"][pos:pos + k][safe], want["action"][safe])
