@@ -379,3 +379,43 @@ def test_many_short_series_and_a_very_wide_one(scorer):
     want = orc.score_series_multivariate(xm, 25, vae_w, lstm_w, None, None, 10.0, dtype=np.float64)
     np.testing.assert_allclose(got["err"], want["err"], rtol=RTOL)
     assert _nrel(got["q"], want["q"]) <= RTOL
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 8))))
+def test_rollout_designs_agree_on_random_networks(scorer, seed):
+    """drl_rollout_batch on random networks, whose Q head changes sign often (many action changes, long fixed-point
+    iterations, long lists of tiles for the sparse passes): the fixed point with sparse passes, the fixed point with
+    full passes only, and the sequential kernel give the same actions and the same Q bits, and the fixed point takes
+    the same number of passes either way.  (Against the numpy oracle such a rollout is chaotic — one near-tie flips
+    everything after it — so that comparison is made on the reference's checkpoints, test_gpu_parity.py.)"""
+    rng = np.random.default_rng(9000 + seed)
+    Wn = int(rng.integers(2, 61))
+    H = int(rng.choice([16, 64, 104, 128, 128]))
+    lstm = synth_lstm(rng, 2, H, 2)
+    n_seg = int(rng.integers(1, 8))
+    lens = [int(rng.integers(max(1, Wn - 3), Wn + 500)) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = Wn + int(rng.integers(1, 400))
+    v = rng.random(sum(lens), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    scorer.set_lstm(lstm)
+    try:
+        scorer.set_rollout_mode("fixed_point")
+        a_sp, q_sp = scorer.rollout(v, Wn, off, return_q=True)
+        passes = scorer.last_rollout_passes
+        os.environ["DRLVAE_ROLLOUT_DENSE"] = "1"
+        try:
+            a_de, q_de = scorer.rollout(v, Wn, off, return_q=True)
+            assert scorer.last_rollout_passes == passes
+        finally:
+            del os.environ["DRLVAE_ROLLOUT_DENSE"]
+        scorer.set_rollout_mode("sequential")
+        a_sq, q_sq = scorer.rollout(v, Wn, off, return_q=True)
+        scorer.set_rollout_mode("auto")
+        a_au = scorer.rollout(v, Wn, off)
+    finally:
+        scorer.set_rollout_mode("auto")
+    K = int(sum(max(0, n - Wn) for n in lens))
+    assert a_sp.shape == (K,) and passes >= 1
+    for a, q in ((a_de, q_de), (a_sq, q_sq)):
+        assert np.array_equal(a, a_sp) and np.array_equal(q.view(np.uint32), q_sp.view(np.uint32)), (Wn, H, lens, passes)
+    assert np.array_equal(a_au, a_sp)
