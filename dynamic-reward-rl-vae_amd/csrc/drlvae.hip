@@ -1339,7 +1339,9 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     // chunks' results are those of the one-shot call, bit for bit (tested).  The get_states_list flag quirk
     // depends on a window's position in its series, so series are not cut in that mode.
     const size_t in_bytes = (size_t)total * F * sizeof(float);
-    const size_t PIPE_MIN = (size_t)16 << 20, CHUNK = (size_t)8 << 20;
+    size_t PIPE_MIN = (size_t)16 << 20;
+    const size_t CHUNK = (size_t)8 << 20;
+    if (const char* e = getenv("DRLVAE_PIPE_MIN")) if (atoll(e) > 0) PIPE_MIN = (size_t)atoll(e);   // tests: pipeline small inputs too
     const bool pipelined = in_bytes >= PIPE_MIN && c->copy_stream && c->copy_ev[0] && getenv("DRLVAE_NO_PIPELINE") == nullptr;
     if (!pipelined) {
         HIP_TRY(c, hipMemcpyAsync(d_in, series, in_bytes, hipMemcpyHostToDevice, c->stream));

@@ -419,3 +419,47 @@ def test_rollout_designs_agree_on_random_networks(scorer, seed):
     for a, q in ((a_de, q_de), (a_sq, q_sq)):
         assert np.array_equal(a, a_sp) and np.array_equal(q.view(np.uint32), q_sp.view(np.uint32)), (Wn, H, lens, passes)
     assert np.array_equal(a_au, a_sp)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 6))))
+def test_pipelined_host_path_random_chunk_plans(scorer, seed):
+    """The chunk planner of drl_score_batch's pipelined path (whole series, window ranges of long series with their
+    halo, series too short for a window in between) on random ragged batches and random chunk sizes: the result is
+    that of the one-shot call, bit for bit, in every output."""
+    rng = np.random.default_rng(7000 + seed)
+    F = int(rng.choice([1, 1, 3, 8]))
+    Wn = int(rng.integers(2, 40))
+    H = 128 if F == 1 and seed % 2 == 0 else 64
+    mode = ["zeros", "quirk", "explicit", "both"][int(rng.integers(0, 4))] if F > 1 or True else "zeros"
+    lstm = synth_lstm(rng, F + 1, H, 2)
+    vae, _, _ = _rand_vae(rng, Wn * F)
+    n_seg = int(rng.integers(1, 9))
+    lens = [int(rng.choice([rng.integers(1, Wn + 2), rng.integers(Wn, 4000), rng.integers(4000, 30000)])) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = int(rng.integers(2000, 30000))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    x = rng.random((int(off[-1]), F), dtype=np.float32)
+    kw = dict(flag_mode=mode, vae_lag=int(rng.integers(0, 2)))
+    if mode == "explicit":
+        kw["flags"] = (rng.random(int(off[-1])) < 0.3).astype(np.float32)
+    if mode == "both":
+        kw["action_rule"] = "wadi"
+    if rng.random() < 0.5:
+        kw["in_scale"] = rng.uniform(0.5, 1.5, n_seg).astype(np.float32)
+        kw["in_offset"] = rng.uniform(-0.2, 0.2, n_seg).astype(np.float32)
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    os.environ["DRLVAE_NO_PIPELINE"] = "1"
+    try:
+        ref = scorer.score(x, Wn, off, **kw)
+    finally:
+        del os.environ["DRLVAE_NO_PIPELINE"]
+    os.environ["DRLVAE_PIPE_MIN"] = "1"
+    os.environ["DRLVAE_PIPE_CHUNK"] = str(int(rng.choice([4 * Wn, 777, 5000, 20000, 100000])))
+    try:
+        got = scorer.score(x, Wn, off, **kw)
+    finally:
+        del os.environ["DRLVAE_PIPE_MIN"], os.environ["DRLVAE_PIPE_CHUNK"]
+    K = int(sum(max(0, n - Wn) for n in lens))
+    assert got["err"].shape == (K,)
+    for k in ref:
+        assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), (k, F, Wn, H, mode, lens)
