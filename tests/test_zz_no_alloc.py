@@ -100,3 +100,63 @@ def test_noalloc_entry_point_rejects_sizes_beyond_its_scratch():
             sc.score_dev(series, W, np.arange(1026, dtype=np.int64) * 30, out, flag_mode="both", noalloc=True)
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DRLVAE_SWEEP_SEEDS", 3))))
+def test_noalloc_calls_back_to_back_without_synchronising(seed):
+    """Several calls of the no-allocation entry point queued on one stream with NO synchronisation in between,
+    each with its own ragged layout, scaler tables and outputs: every call re-uses the one pinned staging block
+    and the one scratch array (tables, then projections) of the call before, in stream order.  Results are those
+    of the allocating entry point, bit for bit."""
+    import torch
+    from drlvae.scorer import WindowScorer
+    rng = np.random.default_rng(4000 + seed)
+    F = int(rng.choice([1, 5, 38]))
+    H = 128 if F == 1 else int(rng.choice([64, 128]))
+    vae, lstm = _nets(rng, F, H)
+    sc = WindowScorer(0)
+    try:
+        sc.set_vae(vae)
+        sc.set_lstm(lstm)
+        dev = torch.device("cuda", sc.device)
+        D = W * F
+        calls = []
+        cap = 16_000 if H > 64 else 32_000                    # samples the scratch array has projections for
+        for _ in range(int(rng.integers(3, 7))):
+            n_seg = int(rng.integers(1, 6))
+            lens = [int(rng.integers(1, cap // n_seg)) for _ in range(n_seg)]
+            lens[int(rng.integers(0, n_seg))] = max(lens[0], W + int(rng.integers(1, 500)))
+            lens = [min(n, cap // n_seg) for n in lens]
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            x = rng.random((int(off[-1]), F), dtype=np.float32)
+            if F > 1:
+                kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=rng.uniform(0.3, 0.7, D),
+                          vae_scale=rng.uniform(0.2, 0.6, D), vae_clip=10.0)
+            else:
+                kw = dict(vae_lag=1, flag_mode=["quirk", "zeros"][int(rng.integers(0, 2))], action_rule="argmax",
+                          in_scale=rng.uniform(0.5, 1.5, n_seg).astype(np.float32),
+                          in_offset=rng.uniform(-0.1, 0.1, n_seg).astype(np.float32))
+            K = int(np.maximum(np.diff(off) - W, 0).sum())
+            S = 2 if kw["flag_mode"] == "both" else 1
+            series = torch.from_numpy(x).to(dev)
+            series = series if F > 1 else series.reshape(-1)
+            outs = [{"err": torch.full((K,), -1.0, dtype=torch.float32, device=dev),
+                     "q": torch.full((K, S, 2), -1.0, dtype=torch.float32, device=dev),
+                     "action": torch.full((K,), -1, dtype=torch.int32, device=dev),
+                     "margin": torch.full((K,), -1.0, dtype=torch.float32, device=dev)} for _ in range(2)]
+            calls.append((series, off, kw, outs, K))
+        torch.cuda.synchronize()
+        for series, off, kw, outs, K in calls:               # queued back to back
+            sc.score_dev(series, W, off, outs[1], noalloc=True, **kw)
+        sc.synchronize()
+        for series, off, kw, outs, K in calls:
+            sc.score_dev(series, W, off, outs[0], noalloc=False, **kw)
+        sc.synchronize()
+        for i, (series, off, kw, outs, K) in enumerate(calls):
+            for k in outs[0]:
+                a, b = outs[0][k].cpu().numpy(), outs[1][k].cpu().numpy()
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (i, k, F, H, off.tolist())
+            if K:
+                assert float(outs[1]["err"].min()) >= 0
+    finally:
+        sc.close()
