@@ -30,7 +30,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) {
     const LstmArgs& a = fa.l;
-    __shared__ __attribute__((aligned(16))) float s_h[32 * 64];            // [k-step][lane]
+    __shared__ __attribute__((aligned(16))) float s_h[2][32 * 64];         // [step parity][k-step][lane]
     __shared__ __attribute__((aligned(16))) float s_bias[32 * 16];
     __shared__ __attribute__((aligned(16))) float s_u[4][(8 - W16_UREG) * 32 * 64 + 4];
     __shared__ float s_sv[H128_SV];
@@ -109,11 +109,12 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) 
                 acc[tl] = mfma16(wx[tl], bx, acc[tl]);
             }
         };
-        auto pointwise = [&](const f32x4 (&acc)[8], float (&c)[8]) {
+        // h_t goes to the buffer h_{t-1} is NOT read from, so a step needs one barrier (h_t complete), not two
+        auto pointwise = [&](const f32x4 (&acc)[8], float (&c)[8], float* __restrict__ hw) {
 #pragma unroll
             for (int tl = 0; tl < 8; ++tl) {
                 const float hv = lstm_cell(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3], fb, c[tl]);
-                s_h[(8 * w + tl) * 64 + lane] = hv;
+                hw[(8 * w + tl) * 64 + lane] = hv;
             }
         };
 
@@ -122,25 +123,26 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) 
 #pragma unroll
         for (int tl = 0; tl < 8; ++tl) c[tl] = 0.0f;
         init(acc, xin(0));
-        pointwise(acc, c);
+        pointwise(acc, c, s_h[1]);
         float nx = xin(W > 1 ? 1 : 0);
         __syncthreads();
         for (int t = 1; t < W; ++t) {
             const float bx = nx;
             nx = xin(t + 1 < W ? t + 1 : t);
             init(acc, bx);
+            const float* __restrict__ hr = s_h[t & 1];          // h_{t-1}
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) {
-                const float b = s_h[kk * 64 + lane];
+                const float b = hr[kk * 64 + lane];
 #pragma unroll
                 for (int tl = 0; tl < W16_UREG; ++tl) acc[tl] = mfma16(U[tl][kk], b, acc[tl]);
 #pragma unroll
                 for (int tl = W16_UREG; tl < 8; ++tl) acc[tl] = mfma16(ul[((tl - W16_UREG) * 32 + kk) * 64 + lane], b, acc[tl]);
             }
-            __syncthreads();                    // every wave has read h_{t-1}
-            pointwise(acc, c);
-            __syncthreads();                    // h_t is complete
+            pointwise(acc, c, s_h[(t + 1) & 1]);
+            __syncthreads();                    // h_t is complete (and every wave has read h_{t-1})
         }
+        const float* __restrict__ hfin = s_h[W & 1];            // h of the last step
 
         // Q head: wave 0, lane (half, window); even and odd units as two chains, as the other kernels do
         if (w == 0 && lane < 32) {
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) 
 #pragma unroll 8
                 for (int m = 0; m < 64; ++m) {
                     const int unit = 2 * m + half;
-                    part = fmaf(s_h[(unit >> 2) * 64 + (unit & 3) * 16 + col], s_wout[unit * a.A + act], part);
+                    part = fmaf(hfin[(unit >> 2) * 64 + (unit & 3) * 16 + col], s_wout[unit * a.A + act], part);
                 }
                 part += __shfl_xor(part, 16);
                 if (half == 0 && col < count)
