@@ -723,8 +723,10 @@ int drl_set_lstm(drl_ctx* c, int in_dim, int hidden, int n_actions, float forget
     if (!kernel || !bias || !w_out || !b_out) return fail(c, DRL_ERR_ARG, "drl_set_lstm: null argument");
     if (in_dim < 1 || n_actions < 2 || n_actions > 8)
         return fail(c, DRL_ERR_ARG, "drl_set_lstm: in_dim %d / n_actions %d out of range", in_dim, n_actions);
-    if (hidden < 8 || hidden > 128 || hidden % 8)
-        return fail(c, DRL_ERR_UNSUPPORTED, "drl_set_lstm: hidden %d (multiples of 8 up to 128 supported)", hidden);
+    // any width up to 128: the packs are zero-padded to 64 or 128 units, and a padded unit stays at c = h = 0
+    // (all four pre-activations 0: sigmoid(0) * tanh(0) = 0), so it adds exact zeros to every sum
+    if (hidden < 1 || hidden > 128)
+        return fail(c, DRL_ERR_UNSUPPORTED, "drl_set_lstm: hidden %d (1..128 supported)", hidden);
     HIP_TRY(c, hipSetDevice(c->device));
     LstmHost l;
     l.I = in_dim; l.H = hidden; l.A = n_actions; l.forget_bias = forget_bias;

@@ -35,13 +35,24 @@ def _nrel(got, want):
 SOAK = "DRLVAE_SWEEP_SEEDS" in os.environ
 
 
-def _q_tol(q32, q64):
+def _q_ok(got, q64, lstm):
     """The bar for Q against the fp64 oracle is 1e-5 of the window's largest |Q| (north_star), and that is what the
     suite's fixed seeds are held to.  The soak run (DRLVAE_SWEEP_SEEDS=300) meets, about once in 150 random
-    networks, one whose Q head cancels to a few percent of its terms; float32 arithmetic itself cannot hold the
-    bar there — the oracle's own float32 run is off its float64 run by 3e-6 .. 7e-6 on those — so the soak run
-    allows eight times the oracle's float32 deviation where that is the larger bound."""
-    return max(RTOL, 8.0 * _nrel(q32, q64)) if SOAK else RTOL
+    networks, one whose Q head cancels to a percent of its terms or less (sum |w_out| = 81 against |Q| = 0.01);
+    no float32 evaluation holds 1e-5 of |Q| there (the numpy float32 oracle is off the float64 one by 3e-6 .. 7e-6
+    of |Q| on those, the kernels — v_exp_f32 / v_rcp_f32, pre-scaled gate weights — by three times that: 4e-7
+    absolute on terms of magnitude 30).  The soak run therefore also accepts an absolute error of two float32 ulps
+    of the head's term scale, 2 * 2^-23 * (sum_u |w_out[u, a]| + |b_out[a]|) (|h| <= 1); for a well-conditioned
+    head that is below the 1e-5 bar and changes nothing."""
+    got = np.asarray(got, np.float64).reshape(len(q64), -1)
+    want = np.asarray(q64, np.float64).reshape(len(q64), -1)
+    if not len(want):
+        return True
+    tol = RTOL * np.abs(want).max(axis=1)
+    if SOAK:
+        scale = float((np.abs(lstm["w_out"]).sum(axis=0) + np.abs(lstm["b_out"])).max())
+        tol = np.maximum(tol, 2.0 * 2.0 ** -23 * scale)
+    return bool((np.abs(got - want).max(axis=1) <= tol).all())
 
 
 def _err_atol(err32, err64):
@@ -63,7 +74,7 @@ def _rand_vae(rng, D):
 def test_univariate_random_shapes(scorer, seed):
     rng = np.random.default_rng(1000 + seed)
     Wn = int(rng.integers(2, 61))
-    H = int(rng.choice([8, 32, 64, 96, 128]))
+    H = int(rng.choice([8, 32, 64, 96, 128, 128, 5, 50, 100, 127]))
     A = int(rng.choice([2, 2, 3, 4]))
     vae, _, _ = _rand_vae(rng, Wn)
     lstm = synth_lstm(rng, 2, H, A)
@@ -112,9 +123,8 @@ def test_univariate_random_shapes(scorer, seed):
             idx = np.arange(k)[:, None] + 1 + np.arange(Wn)[None, :]
             S[:, :, 1] = fl[idx]
         q = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float64)
-        q32 = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float32)
         np.testing.assert_allclose(out["err"][pos:pos + k], err, rtol=RTOL, atol=_err_atol(err32, err), err_msg=f"W={Wn} H={H}")
-        assert _nrel(out["q"][pos:pos + k], q) <= _q_tol(q32, q), (Wn, H, A, mode, device_minmax, scorer.lstm_variant)
+        assert _q_ok(out["q"][pos:pos + k], q, lstm), (Wn, H, A, mode, device_minmax, scorer.lstm_variant, _nrel(out["q"][pos:pos + k], q))
         srt = np.sort(q, axis=1)
         safe = (srt[:, -1] - srt[:, -2]) > 4 * RTOL * np.abs(q).max(axis=1)
         assert np.array_equal(out["action"][pos:pos + k][safe], np.argmax(q, axis=1)[safe])
@@ -129,7 +139,7 @@ def test_multivariate_random_shapes(scorer, seed):
     rng = np.random.default_rng(2000 + seed)
     Wn = int(rng.integers(3, 31))
     F = int(rng.choice([2, 5, 17, 40]))
-    H = int(rng.choice([16, 40, 64, 104, 128]))
+    H = int(rng.choice([16, 40, 64, 104, 128, 3, 37, 65, 125]))
     D = Wn * F
     vae, hid, dec = _rand_vae(rng, D)
     lstm = synth_lstm(rng, F + 1, H)
@@ -165,7 +175,7 @@ def test_multivariate_random_shapes(scorer, seed):
         want32 = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float32)
         np.testing.assert_allclose(out["err"][pos:pos + k], want["err"], rtol=RTOL, atol=_err_atol(want32["err"], want["err"]),
                                    err_msg=f"W={Wn} F={F} hid={hid} dec={dec} {scorer._lib.drl_last_lstm_variant(scorer._h)}")
-        assert _nrel(out["q"][pos:pos + k], want["q"]) <= _q_tol(want32["q"], want["q"]), (Wn, F, H, scorer.lstm_variant)
+        assert _q_ok(out["q"][pos:pos + k], want["q"], lstm), (Wn, F, H, scorer.lstm_variant, _nrel(out["q"][pos:pos + k], want["q"]))
         m = np.abs(want["q"][:, 1, 1] - want["q"][:, 0, 0])
         safe = m > 4 * RTOL * np.abs(want["q"]).max(axis=(1, 2))
         assert np.array_equal(out["action"][pos:pos + k][safe], want["action"][safe])
@@ -390,7 +400,7 @@ def test_rollout_designs_agree_on_random_networks(scorer, seed):
     everything after it — so that comparison is made on the reference's checkpoints, test_gpu_parity.py.)"""
     rng = np.random.default_rng(9000 + seed)
     Wn = int(rng.integers(2, 61))
-    H = int(rng.choice([16, 64, 104, 128, 128]))
+    H = int(rng.choice([16, 64, 104, 128, 128, 7, 77]))
     lstm = synth_lstm(rng, 2, H, 2)
     n_seg = int(rng.integers(1, 8))
     lens = [int(rng.integers(max(1, Wn - 3), Wn + 500)) for _ in range(n_seg)]
