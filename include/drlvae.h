@@ -117,7 +117,8 @@ int drl_set_vae(drl_ctx* ctx, int n_layers, const int32_t* in_dims, const int32_
  * static_rnn with zero initial state, kernel [in_dim+hidden, 4*hidden] with gate column blocks
  * i|j|f|o, followed by Q = h_T.w_out + b_out.  in_dim = F + 1 (features + the action flag); a network
  * without the flag channel (in_dim = F: the legacy RLVAL / AdaptiveTauRL estimators) is scored with
- * DRL_FLAG_ZEROS. */
+ * DRL_FLAG_ZEROS.  Limits: hidden 1..128 (the reference uses 128 and 64), n_actions 2..8; beyond them
+ * DRL_ERR_UNSUPPORTED / DRL_ERR_ARG. */
 int drl_set_lstm(drl_ctx* ctx, int in_dim, int hidden, int n_actions, float forget_bias,
                  const float* kernel, const float* bias, const float* w_out, const float* b_out);
 
