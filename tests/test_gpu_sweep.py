@@ -473,3 +473,35 @@ def test_pipelined_host_path_random_chunk_plans(scorer, seed):
     assert got["err"].shape == (K,)
     for k in ref:
         assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), (k, F, Wn, H, mode, lens)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 6))))
+def test_al_selection_random_batches(scorer, seed):
+    """drl_al_get_samples on random ragged batches: the device selection is numpy's stable ranking of the device's
+    own margins with the already-labelled windows removed, first N (reference myasp-A1.py:250-259); duplicate and
+    out-of-range entries in already_selected, N larger than what is left, exact ties (a constant series gives every
+    window the same margin: ties keep window order)."""
+    rng = np.random.default_rng(11000 + seed)
+    Wn = int(rng.integers(2, 40))
+    H = int(rng.choice([64, 128, 24]))
+    lstm = synth_lstm(rng, 2, H, 2)
+    n_seg = int(rng.integers(1, 7))
+    lens = [int(rng.integers(1, 3000)) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = Wn + int(rng.integers(1, 3000))
+    v = rng.random(sum(lens), dtype=np.float32)
+    if seed % 4 == 3:
+        v[:] = 0.5                                            # every window identical: all margins tie
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    K = int(sum(max(0, n - Wn) for n in lens))
+    n_sel = int(rng.integers(0, max(1, K // 2)))
+    already = [int(i) for i in rng.integers(0, K, n_sel)]      # may repeat
+    if seed % 3 == 0:
+        already += [K + 5, -3]                                # out of range: ignored
+    N = int(rng.choice([0, 1, 10, 1000, K + 10]))
+    scorer.set_lstm(lstm)
+    idx, margin = scorer.al_get_samples(v, Wn, N, already, offsets=off, flag_mode=["quirk", "zeros"][seed % 2],
+                                        return_margin=True)
+    assert margin.shape == (K,)
+    sel = set(i for i in already if 0 <= i < K)
+    want = [int(i) for i in np.argsort(margin, kind="stable") if int(i) not in sel][:N]
+    assert idx == want, (Wn, H, lens, N, len(sel))
