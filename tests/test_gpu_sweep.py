@@ -505,3 +505,52 @@ def test_al_selection_random_batches(scorer, seed):
     sel = set(i for i in already if 0 <= i < K)
     want = [int(i) for i in np.argsort(margin, kind="stable") if int(i) not in sel][:N]
     assert idx == want, (Wn, H, lens, N, len(sel))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 8))))
+def test_estimator_predict_random_batches(scorer, seed):
+    """drl_q_predict (estimator.predict on explicit states) on random shapes and batch sizes: a state's Q does not
+    depend on the batch it arrives in — one by one (the matrix-vector kernel), as a whole batch (matrix-vector or
+    MFMA kernels, by size), and through the fallback kernel — bit for bit; and it is the oracle's to 1e-5.
+    drl_vae_predict likewise: rows one by one equal the batch."""
+    rng = np.random.default_rng(13000 + seed)
+    I = int(rng.choice([1, 2, 2, 3, 9, 39, 124]))
+    H = int(rng.choice([64, 128, 128, 40, 100]))
+    A = int(rng.choice([2, 2, 3]))
+    Wn = int(rng.integers(1, 64))
+    B = int(rng.choice([1, 2, 5, 33, 300, 2100]))
+    lstm = synth_lstm(rng, I, H, A)
+    lstm["kernel"][:I] *= min(1.0, 4.0 / I)                  # keep the pre-activations in the cell's active range
+    scorer.set_lstm(lstm)
+    S = rng.random((B, Wn, I), dtype=np.float32)
+    q = scorer.q_predict(S)
+    variant = scorer.lstm_variant
+    want = orc.lstm_q(S, lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0, dtype=np.float64)
+    assert _q_ok(q, want, lstm), (I, H, A, Wn, B, variant, _nrel(q, want))
+    pick = sorted(set(int(i) for i in rng.integers(0, B, 4)))
+    for i in pick:
+        one = scorer.q_predict(S[i:i + 1])
+        assert np.array_equal(one.view(np.uint32), q[i:i + 1].view(np.uint32)), (I, H, Wn, B, i, variant, scorer.lstm_variant)
+    os.environ["DRLVAE_FORCE_GENERIC"] = "1"
+    try:
+        from drlvae.scorer import WindowScorer
+        g = WindowScorer(0)
+        try:
+            g.set_lstm(lstm)
+            qg = g.q_predict(S[:64])
+            assert g.lstm_variant in ("generic", "gemv", "h128i2")     # the univariate H > 64 net has its own explicit-state kernel
+            assert np.array_equal(qg.view(np.uint32), q[:64].view(np.uint32)), (I, H, Wn, B, variant, g.lstm_variant)
+        finally:
+            g.close()
+    finally:
+        del os.environ["DRLVAE_FORCE_GENERIC"]
+    D = int(rng.integers(2, 200))
+    vae, _, _ = _rand_vae(rng, D)
+    scorer.set_vae(vae)
+    X = rng.random((int(rng.choice([1, 3, 40, 700])), D), dtype=np.float32)
+    rec, err = scorer.vae_predict(X, return_err=True)
+    r64 = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], 10.0, dtype=np.float64)
+    np.testing.assert_allclose(rec, r64, rtol=RTOL, atol=2e-7)
+    for i in sorted(set(int(i) for i in rng.integers(0, len(X), 3))):
+        r1, e1 = scorer.vae_predict(X[i:i + 1], return_err=True)
+        assert np.array_equal(r1.view(np.uint32), rec[i:i + 1].view(np.uint32)) and e1[0] == err[i], (D, len(X), i)
