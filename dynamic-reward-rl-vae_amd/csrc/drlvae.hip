@@ -76,7 +76,7 @@ struct LstmHost {
 
 struct Prof {
     bool on = false;
-    struct Pair { hipEvent_t a, b; int which; };
+    struct Pair { hipEvent_t a, b; int which; bool a_shared; };   // a_shared: a is the pair before's b (not returned to the pool twice)
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;
     double ms[2] = {0, 0};
@@ -234,15 +234,19 @@ void pack_bias(const float* b, int dout, float* dst, double scale) {
             }
 }
 
-void prof_begin(drl_ctx* c, int which, hipStream_t st) {
+// chain: nothing has been queued on `st` since the end event of the pair before, so that event is this pair's
+// start as well (an event record costs the stream ~5 us between two kernels: one per boundary, not two)
+void prof_begin(drl_ctx* c, int which, hipStream_t st, bool chain = false) {
     if (!c->prof.on) return;
     Prof::Pair p;
+    p.a_shared = chain && !c->prof.pending.empty() && c->prof.pending.back().b;
     for (hipEvent_t* e : {&p.a, &p.b}) {
+        if (e == &p.a && p.a_shared) { p.a = c->prof.pending.back().b; continue; }
         if (!c->prof.pool.empty()) { *e = c->prof.pool.back(); c->prof.pool.pop_back(); }
         else if (hipEventCreate(e) != hipSuccess) { *e = nullptr; }
     }
     p.which = which;
-    if (p.a) (void)hipEventRecord(p.a, st);
+    if (p.a && !p.a_shared) (void)hipEventRecord(p.a, st);
     c->prof.pending.push_back(p);
 }
 void prof_end(drl_ctx* c, hipStream_t st) {
@@ -259,7 +263,7 @@ int prof_collect(drl_ctx* c) {
             c->prof.ms[p.which] += ms;
             c->prof.n[p.which] += 1;
         }
-        if (p.a) c->prof.pool.push_back(p.a);
+        if (p.a && !p.a_shared) c->prof.pool.push_back(p.a);
         if (p.b) c->prof.pool.push_back(p.b);
     }
     c->prof.pending.clear();
@@ -520,7 +524,7 @@ void drl_destroy(drl_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)drl_comm_destroy(c);
-    for (auto& p : c->prof.pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+    for (auto& p : c->prof.pending) { if (p.a && !p.a_shared) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
     for (auto e : c->prof.pool) (void)hipEventDestroy(e);
     for (auto& sl : c->seg_slots) {
         if (sl.dev.p) (void)hipFree(sl.dev.p);
@@ -1095,6 +1099,11 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         a.flag_mode = o->flag_mode; a.flags = d_flags; a.seg = seg;
         a.S = o->flag_mode == DRL_FLAG_BOTH ? 2 : 1;
         a.q = d_q;
+        // argmax epilogue inside the LSTM kernel whenever the workgroup that computes a window's Q holds every
+        // value the rule needs: one candidate state, or both candidates in one wave (lstm_rec2_kernel for
+        // every tile).  Otherwise finalize_kernel below.  DRLVAE_NO_FUSED_EPILOGUE=1: always finalize_kernel (tests).
+        bool fused_epilogue = (d_action || d_margin) && a.S == 1 && getenv("DRLVAE_NO_FUSED_EPILOGUE") == nullptr;
+        if (fused_epilogue) { a.action = d_action; a.margin = d_margin; a.rule = o->action_rule; }
         // hidden widths 65..128 are packed zero-padded to 16 gate tiles x 64 k-steps (padded units stay at h = 0)
         const bool fast = c->lstm.I == 2 && c->lstm.NT == 16 && F == 1 && W >= 2 && W + 65 <= H128_SV;
         // the other shapes project every sample once (1 KiB per sample for H <= 64, 2 KiB above: C4 177 MB).  When
@@ -1112,7 +1121,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             }
         }
         c->last_tile = 0;
-        if (prof) prof_begin(c, 0, c->stream);
+        if (prof) prof_begin(c, 0, c->stream, want_vae && !overlap);   // serial: the VAE kernel's end event is the start
         if (fast && c->tl_n > 0 && c->lstm.has16) {
             // a sparse pass of the rollout's fixed point: only the listed 16-window tiles
             a.seg.tile_off = sh.d_t16; a.n_tiles = c->tl_n; a.tile_list = c->tl_dev;
@@ -1214,6 +1223,10 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 const int n2 = c->rec2_mode == 0 ? 0 : c->rec2_mode == 2 ? sh.tiles32
                                : overlap ? 0
                                : 2 * rem <= slots ? sh.tiles32 - rem : sh.tiles32;
+                if (n2 == sh.tiles32 && (d_action || d_margin) && getenv("DRLVAE_NO_FUSED_EPILOGUE") == nullptr) {
+                    fused_epilogue = true;
+                    ra.l.action = d_action; ra.l.margin = d_margin; ra.l.rule = o->action_rule;
+                }
                 if (n2 > 0) {
                     ra.l.n_tiles = n2; ra.tile0 = 0;
                     hipLaunchKernelGGL(lstm_rec2_kernel<8>, dim3((n2 + 3) / 4), dim3(256), lds, c->stream, ra);
@@ -1240,7 +1253,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         }
-        if (d_action || d_margin) {
+        if ((d_action || d_margin) && !fused_epilogue) {
             const int bs = 256;
             hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((sh.K_total + bs - 1) / bs)), dim3(bs), 0, c->stream,
                                d_q, sh.K_total, a.S, c->lstm.A, o->action_rule, d_action, d_margin);

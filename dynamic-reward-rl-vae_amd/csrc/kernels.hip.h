@@ -453,6 +453,29 @@ struct LstmArgs {
     int S;                  // candidate states per window (gridDim.y)
     float* q;               // [K_total, S, A]
     const int* tile_list;   // null, or the n_tiles tile indices to work on (the sparse passes of drl_rollout_batch)
+    // argmax epilogue (reference myasp-A1.py:227 np.argmax; :255 AL margin; myasp-wadi.py:328 WaDi rule): when the
+    // kernel that computes a window's Q holds all the values the rule needs, it writes action and margin itself
+    // (host: fused_epilogue); otherwise finalize_kernel does, from q.  Either may be null.
+    int* action;            // [K_total]
+    float* margin;          // [K_total]
+    int rule;               // drl_action_rule
+};
+
+// np.argmax over the actions of one state, ties -> the first, and |q0 - q1|: the operations of finalize_kernel
+struct ActEpi {
+    float q0, q1, bv;
+    int best;
+    __device__ __forceinline__ void push(int act, float v) {
+        if (act == 0) { q0 = v; bv = v; best = 0; }
+        else {
+            if (act == 1) q1 = v;
+            if (v > bv) { bv = v; best = act; }
+        }
+    }
+    __device__ __forceinline__ void store(const LstmArgs& a, long long win) const {
+        if (a.action) a.action[win] = best;
+        if (a.margin) a.margin[win] = fabsf(q0 - q1);
+    }
 };
 
 __device__ __forceinline__ float synth_flag(int mode, long long k, int t, int W, int cand,
@@ -552,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void lstm_generic_kernel(LstmArgs a) {
     }
 
     // Q head: lane holds units 8*tl + 2*qd + half of window j
+    ActEpi epi;
     for (int act = 0; act < a.A; ++act) {
         float part = 0.0f;
         for (int kk = 0; kk < NT * 4; ++kk) {
@@ -559,9 +583,12 @@ __global__ __launch_bounds__(256, 1) void lstm_generic_kernel(LstmArgs a) {
             if (unit < a.H) part = fmaf(hw[kk * 64], a.w_out[unit * a.A + act], part);
         }
         part += __shfl_xor(part, 32);
+        const float qv = part + a.b_out[act];
+        epi.push(act, qv);
         if (half == 0 && j < count)
-            a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = part + a.b_out[act];
+            a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = qv;
     }
+    if (a.S == 1 && half == 0 && j < count) epi.store(a, a.seg.win_off[s] + k0 + j);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -783,6 +810,7 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
                                      voff0 + (unsigned)tn * 32u, flag_of(t), half);
     }
 
+    ActEpi epi;
     for (int act = 0; act < a.A; ++act) {
         float part = 0.0f;
 #pragma unroll
@@ -793,9 +821,12 @@ __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecAr
                 part = fmaf(h[tl][qd], unit < a.H ? a.w_out[unit * a.A + act] : 0.0f, part);
             }
         part += __shfl_xor(part, 32);
+        const float qv = part + a.b_out[act];
+        epi.push(act, qv);
         if (half == 0 && j < count)
-            a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = part + a.b_out[act];
+            a.q[((a.seg.win_off[s] + k0 + j) * a.S + cand) * a.A + act] = qv;
     }
+    if (a.S == 1 && half == 0 && j < count) epi.store(a, a.seg.win_off[s] + k0 + j);
 }
 
 // Two candidate states per window (DRL_FLAG_BOTH: the flag column is 0 on every row of candidate 0 and
@@ -909,6 +940,10 @@ __global__ __launch_bounds__(256, 1) void lstm_rec2_kernel(RecArgs ra) {
                              voff0 + (unsigned)tn * 32u, half);
     }
 
+    // the wave holds the Q of both candidate states: np.argmax over candidate 0's actions (rule 0), or the WaDi
+    // rule, Q(s1)[1] > Q(s0)[0] (finalize_kernel's operations)
+    ActEpi epi;
+    float q1_wadi = 0.0f;
 #pragma unroll
     for (int cd = 0; cd < 2; ++cd)
         for (int act = 0; act < a.A; ++act) {
@@ -921,9 +956,16 @@ __global__ __launch_bounds__(256, 1) void lstm_rec2_kernel(RecArgs ra) {
                     part = fmaf(h[cd][tl][qd], unit < a.H ? a.w_out[unit * a.A + act] : 0.0f, part);
                 }
             part += __shfl_xor(part, 32);
+            const float qv = part + a.b_out[act];
+            if (cd == 0) epi.push(act, qv);
+            else if (act == 1) q1_wadi = qv;
             if (half == 0 && j < count)
-                a.q[((a.seg.win_off[s] + k0 + j) * 2 + cd) * a.A + act] = part + a.b_out[act];
+                a.q[((a.seg.win_off[s] + k0 + j) * 2 + cd) * a.A + act] = qv;
         }
+    if (half == 0 && j < count) {
+        if (a.rule == 1) { epi.q1 = q1_wadi; epi.best = q1_wadi > epi.q0 ? 1 : 0; }
+        epi.store(a, a.seg.win_off[s] + k0 + j);
+    }
 }
 
 // Univariate fast path (I = 2, H = 128): one workgroup of 4 waves = 64 consecutive windows in two
@@ -1134,15 +1176,19 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
         if (w < NG) {
             const float* hb = w == 0 ? hA : hB;
             const int jw = w * 32 + j;
+            ActEpi epi;
             for (int act = 0; act < a.A; ++act) {
                 float part = 0.0f;
 #pragma unroll 8
                 for (int kk = 0; kk < 64; ++kk)
                     part = fmaf(hb[kk * 64 + lane], s_wout[((kk >> 2) * 8 + 2 * (kk & 3) + half) * a.A + act], part);
                 part += __shfl_xor(part, 32);
+                const float qv = part + a.b_out[act];
+                epi.push(act, qv);
                 if (half == 0 && jw < count)
-                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = qv;
             }
+            if (a.S == 1 && half == 0 && jw < count) epi.store(a, sg.win0 + k0 + jw);
         }
         __syncthreads();        // h and the staged samples are rewritten by the next tile
     }
@@ -1286,15 +1332,19 @@ __global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
         if (w < NG) {
             const float* hb = w == 0 ? hA : hB;
             const int jw = w * 32 + j;
+            ActEpi epi;
             for (int act = 0; act < a.A; ++act) {
                 float part = 0.0f;
 #pragma unroll 8
                 for (int kk = 0; kk < 64; ++kk)
                     part = fmaf(hb[kk * 64 + lane], s_wout[((kk >> 2) * 8 + 2 * (kk & 3) + half) * a.A + act], part);
                 part += __shfl_xor(part, 32);
+                const float qv = part + a.b_out[act];
+                epi.push(act, qv);
                 if (half == 0 && jw < count)
-                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = qv;
             }
+            if (a.S == 1 && half == 0 && jw < count) epi.store(a, sg.win0 + k0 + jw);
         }
         __syncthreads();
     }

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_f16x3_kernel(LstmF16Args f
             const _Float16* hh = w == 0 ? s_hiA : s_hiB;
             const _Float16* hl = w == 0 ? s_loA : s_loB;
             const int jw = w * 32 + j;
+            ActEpi epi;
             for (int act = 0; act < a.A; ++act) {
                 float part = 0.0f;
                 for (int g = 8 * half; g < 8 * half + 8; ++g)
@@ -223,9 +224,12 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_f16x3_kernel(LstmF16Args f
                         part = fmaf(hv, s_wout[(8 * g + 2 * (i & 3) + (i >> 2)) * a.A + act], part);
                     }
                 part += __shfl_xor(part, 32);
+                const float qv = part + a.b_out[act];
+                epi.push(act, qv);
                 if (half == 0 && jw < count)
-                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = part + a.b_out[act];
+                    a.q[((sg.win0 + k0 + jw) * a.S + cand) * a.A + act] = qv;
             }
+            if (a.S == 1 && half == 0 && jw < count) epi.store(a, sg.win0 + k0 + jw);
         }
         __syncthreads();        // h and the staged samples are rewritten by the next tile
     }

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) 
         // Q head: wave 0, lane (half, window); even and odd units as two chains, as the other kernels do
         if (w == 0 && lane < 32) {
             const int half = lane >> 4;
+            ActEpi epi;
             for (int act = 0; act < a.A; ++act) {
                 float part = 0.0f;
 #pragma unroll 8
@@ -155,9 +156,12 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_w16_kernel(Lstm16Args fa) 
                     part = fmaf(hfin[(unit >> 2) * 64 + (unit & 3) * 16 + col], s_wout[unit * a.A + act], part);
                 }
                 part += __shfl_xor(part, 16);
+                const float qv = part + a.b_out[act];
+                epi.push(act, qv);
                 if (half == 0 && col < count)
-                    a.q[((sg.win0 + k0 + col) * a.S + cand) * a.A + act] = part + a.b_out[act];
+                    a.q[((sg.win0 + k0 + col) * a.S + cand) * a.A + act] = qv;
             }
+            if (a.S == 1 && half == 0 && col < count) epi.store(a, sg.win0 + k0 + col);
         }
         __syncthreads();
     }

@@ -554,3 +554,49 @@ def test_estimator_predict_random_batches(scorer, seed):
     for i in sorted(set(int(i) for i in rng.integers(0, len(X), 3))):
         r1, e1 = scorer.vae_predict(X[i:i + 1], return_err=True)
         assert np.array_equal(r1.view(np.uint32), rec[i:i + 1].view(np.uint32)) and e1[0] == err[i], (D, len(X), i)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 8))))
+def test_argmax_epilogue_in_the_lstm_kernels_equals_finalize_kernel(scorer, seed):
+    """Action and margin are written by the LSTM kernel's own epilogue whenever the workgroup that computes a
+    window's Q holds every value the rule needs (one candidate state; both candidates in one wave), by
+    finalize_kernel from q otherwise.  Both must give the same actions and margins, bit for bit, and the margin
+    is |q0 - q1| of the q that was written."""
+    rng = np.random.default_rng(15000 + seed)
+    F = int(rng.choice([1, 1, 4, 20]))
+    H = int(rng.choice([128, 64, 30])) if F > 1 else int(rng.choice([128, 128, 64, 90]))
+    A = int(rng.choice([2, 2, 3, 5])) if F == 1 else 2
+    Wn = int(rng.integers(1, 50))
+    lstm = synth_lstm(rng, F + 1, H, A)
+    lstm["b_out"] = (rng.normal(size=A) * 0.05).astype(np.float32)
+    n_seg = int(rng.integers(1, 6))
+    lens = [int(rng.integers(1, 2500)) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = Wn + int(rng.integers(1, 2500))
+    x = rng.random((sum(lens), F), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    if F > 1 and seed % 2 == 0:
+        kw = dict(flag_mode="both", action_rule="wadi", vae_lag=0)
+    elif F > 1:
+        kw = dict(flag_mode="both", action_rule="argmax", vae_lag=0)
+    else:
+        kw = dict(flag_mode=["quirk", "zeros"][seed % 2])
+    sc = _rec2_scorer() if (F > 1 and seed % 4 < 2) else scorer       # both candidates in one wave for every tile
+    sc.set_lstm(lstm)
+    xs = x if F > 1 else x[:, 0]
+    got = sc.score(xs, Wn, off, want=("q", "action", "margin"), **kw)
+    os.environ["DRLVAE_NO_FUSED_EPILOGUE"] = "1"
+    try:
+        ref = sc.score(xs, Wn, off, want=("q", "action", "margin"), **kw)
+    finally:
+        del os.environ["DRLVAE_NO_FUSED_EPILOGUE"]
+    for k in ("q", "action", "margin"):
+        assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), (k, F, H, A, Wn, kw, sc.lstm_variant)
+    q = got["q"]
+    if kw.get("action_rule") == "wadi":
+        q0, q1 = q[:, 0, 0], q[:, 1, 1]
+        assert np.array_equal(got["action"], (q1 > q0).astype(np.int32))
+    else:
+        qa = q[:, 0, :] if q.ndim == 3 else q
+        q0, q1 = qa[:, 0], qa[:, 1]
+        assert np.array_equal(got["action"], np.argmax(qa, axis=1).astype(np.int32))
+    assert np.array_equal(got["margin"], np.abs(q0 - q1))
