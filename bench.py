@@ -411,6 +411,36 @@ def main():
     variant = sc.lstm_variant  # of the headline run (the alt run below changes it)
     overlapped = sc.overlapped
 
+    # When the VAE kernel ran on the second stream beside the LSTM kernels, the per-kernel durations above share
+    # one time span.  A few untimed steps on a second context with the overlap off give each kernel's own duration
+    # (reported beside the roofline line, never as `value`).
+    alone = None
+    if overlapped and rank == 0:
+        os.environ["DRLVAE_OVERLAP"] = "0"
+        try:
+            sc1 = WindowScorer(local)
+        finally:
+            del os.environ["DRLVAE_OVERLAP"]
+        try:
+            sc1.set_vae(wl["vae"])
+            sc1.set_lstm(wl["lstm"])
+            sc1.set_stream(stream.cuda_stream)
+            n1 = max(2, min(args.steps, 5))
+            for _ in range(2):
+                sc1.score_dev(series, wl["W"], wl["offsets"], outs[0], **wl["kw"])
+            sc1.synchronize()
+            sc1.profile(True)
+            sc1.profile_reset()
+            for _ in range(n1):
+                sc1.score_dev(series, wl["W"], wl["offsets"], outs[0], **wl["kw"])
+            sc1.synchronize()
+            (l_ms, l_n), (v_ms, v_n) = sc1.profile_read(0), sc1.profile_read(1)
+            alone = {"lstm_kernels_avg_ms": l_ms / max(l_n, 1), "vae_kernel_avg_ms": v_ms / max(v_n, 1), "steps": n1,
+                     "what": "the same call with DRLVAE_OVERLAP=0 (one stream): each kernel's own duration"}
+        finally:
+            sc1.close()
+        torch.cuda.synchronize()
+
     # the rate of ONE GPU on this same workload with the collective off (rank 0's own kernels, same steps):
     # what a weak-scaling efficiency of this line should be read against (the N = 1 default is another workload)
     single = None
@@ -485,8 +515,12 @@ def main():
             res["roofline"]["algorithmic_flop_per_launch"] = algorithmic
             res["roofline"]["algorithmic_frac"] = algorithmic / lstm_avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS if lstm_n else 0.0
         if overlapped:
-            res["roofline"]["note"] = ("the VAE kernel runs on a second stream beside the LSTM kernels: avg_launch_ms is "
-                                       "the LSTM kernels' span while they share the CUs with it")
+            res["roofline"]["note"] = ("the VAE kernel runs on a second stream beside the LSTM kernels: avg_launch_ms and "
+                                       "vae_kernel_avg_ms are the spans of kernels that share the CUs with each other; "
+                                       "kernels_alone holds each kernel's own duration (a few steps on one stream)")
+            if alone is not None:
+                alone["lstm_frac_alone"] = executed / (alone["lstm_kernels_avg_ms"] / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                res["roofline"]["kernels_alone"] = alone
         tr = res["roofline"]["traffic"]
         if tr and lstm_avg_s > 0:
             # the other roofline, for the record: this path sits at a fraction of a percent of HBM
