@@ -12,6 +12,15 @@ One "step" = one pass of the hot path over one batch of series resident in HBM
 With N > 1 the per-window scores are all-gathered over RCCL (one packed block per rank per step,
 drlvae.dist.ScorePack), the only collective of the path.
 
+At N = 1 the same JSON line also carries (never in `value`):
+  other_configs        every other BASELINE config on this GPU — C5 (4e6 windows per step, >= 1 s of sustained
+                       load), C3, C4, C1 — each with its rate, ms per step, LSTM kernel, executed roofline
+                       fraction and, where the call overlaps its kernels, each kernel's own duration;
+  host_path            drl_score_batch (pageable numpy in, numpy out: the reference's drop-in call) on C2 and C4;
+  library              drl_version (with the hash of the sources it was built from) against the tree's hash.
+They ride on the flag-less run only (an explicit --workload is one workload); --no-others also drops
+roofline.kernels_alone (the PMC passes use it: one launch population per kernel).
+
 `python bench.py --gpus N` from a bare shell starts the N ranks itself (a child
 `python -m torch.distributed.run`, before anything touches the GPU); under a launcher (WORLD_SIZE set)
 it is one rank.  Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
@@ -152,7 +161,7 @@ def cpu_baseline(wl):
     """The oracle (fp32 CPU restatement of the reference's path, batched per series) timed on the host
     cores of this box on a bounded sample of the same workload: the numpy restatement (oracle/ref_path.py,
     BLAS threads) is the headline leg, the torch-CPU one (oracle/ref_path_torch.py) rides beside it
-    (SURVEY.md 8d names both), and ~2 s of the reference's own batch-1 call pattern."""
+    (SURVEY.md 8d names both), and ~1 s of the reference's own batch-1 call pattern: ~8 s in all."""
     from oracle import ref_path as orc
     from oracle import ref_path_torch as orct
     import torch
@@ -184,19 +193,19 @@ def cpu_baseline(wl):
 
     done, passes, dt = leg(lambda v: orc.score_series_univariate(v, W, wl["vae"], wl["lstm"], uni_mode),
                            lambda m: orc.score_series_multivariate(m, W, wl["vae"], wl["lstm"], wl["kw"]["vae_center"],
-                                                                   wl["kw"]["vae_scale"], 10.0), 8.0)
+                                                                   wl["kw"]["vae_scale"], 10.0), 4.0)
     tthreads = torch.get_num_threads()
     tdone, tpasses, tdt = leg(lambda v: orct.score_series_univariate(v, W, wl["vae"], wl["lstm"], uni_mode),
                               lambda m: orct.score_series_multivariate(m, W, wl["vae"], wl["lstm"], wl["kw"]["vae_center"],
-                                                                       wl["kw"]["vae_scale"], 10.0), 6.0)
+                                                                       wl["kw"]["vae_scale"], 10.0), 3.0)
     # the reference's own call pattern (one vae.predict + one estimator.predict per window, batch 1:
-    # SURVEY.md 3.1), ~2 s of it, reported beside the batched figure
+    # SURVEY.md 3.1), ~1 s of it, reported beside the batched figure
     b1 = None
     if F == 1:
         v = x[off[0]:off[1], 0]
         vae, lstm = wl["vae"], wl["lstm"]
         n1, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < 2.0 and n1 + W + 1 < len(v):
+        while time.perf_counter() - t1 < 1.0 and n1 + W + 1 < len(v):
             xw = v[n1:n1 + W][None, :]
             rec = orc.vae_forward(xw, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], 10.0)
             orc.recon_error(xw, rec)
@@ -216,28 +225,166 @@ def cpu_baseline(wl):
                       f"~100x slower, BASELINE.md)"}
 
 
-def pmc_traffic(name, variant):
-    """HBM bytes per launch of the dominant kernel (the LSTM variant that ran) from the committed
-    rocprofv3 PMC summary of the same workload (profiles/rNN/<workload>_pmc_summary.json, newest round),
-    or None."""
-    kerns = {"h128i2": ["lstm_h128i2_kernel"], "h128i2_f16x3": ["lstm_h128i2_f16x3_kernel"],
-             "xproj+rec": ["xproj_kernel", "lstm_rec"], "xproj+h128": ["xproj_kernel", "lstm_h128p_kernel"],
-             "generic": ["lstm_generic_kernel"]}.get(variant, ["lstm_"])
+def pmc_traffic(name, kernels):
+    """HBM-side bytes per scoring call of the LSTM kernels that ran (`kernels`: their rocprofv3 names, from
+    drl_last_lstm_kernels), each kernel's per-launch average in the committed PMC summary of the same workload
+    (profiles/rNN/<workload>_pmc_summary.json, newest round; made from `bench.py --no-others` runs, so every
+    kernel has ONE launch population).  None when a kernel that ran has no row there."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{name}_pmc_summary.json"))):
         best = f
-    if not best:
+    if not best or not kernels:
         return None
     try:
-        d = json.load(open(best))
-        tot = 0.0
-        for k, v in d["kernels"].items():
-            if any(kn in k for kn in kerns) and "hbm_bytes_per_launch" in v:
-                tot += v["hbm_bytes_per_launch"]
-        return tot or None
-    except Exception:
+        rows = {k.replace("void ", "").strip(): v for k, v in json.load(open(best))["kernels"].items()}
+        return float(sum(rows[k]["hbm_bytes_per_launch"] for k in kernels))
+    except (KeyError, ValueError, OSError):
         return None
+
+
+def executed_flop(wl, variant):
+    """Flop one LSTM launch really executes: the xproj paths project each SAMPLE once, not each window's W rows."""
+    H, F, W, S, K = wl["H"], wl["F"], wl["W"], wl["S"], wl["K"]
+    if variant.startswith("xproj"):
+        return int(wl["series"].shape[0]) * 2 * F * 4 * H + K * S * (W * 2 * H * 4 * H + 2 * H * 2)
+    return wl["lstm_flops"] * K
+
+
+def kernels_alone(wl, local, stream, series, out, steps):
+    """Each kernel's own duration: the same call on a second context with the VAE kernel kept on the LSTM
+    kernels' stream (knob overlap = 0), a few untimed steps."""
+    from drlvae.scorer import WindowScorer
+    sc1 = WindowScorer(local)
+    try:
+        sc1.set_knob("overlap", 0)
+        sc1.set_vae(wl["vae"])
+        sc1.set_lstm(wl["lstm"])
+        sc1.set_stream(stream.cuda_stream)
+        for _ in range(2):
+            sc1.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
+        sc1.synchronize()
+        sc1.profile(True)
+        sc1.profile_reset()
+        for _ in range(steps):
+            sc1.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
+        sc1.synchronize()
+        (l_ms, l_n), (v_ms, v_n) = sc1.profile_read(0), sc1.profile_read(1)
+        l_avg = l_ms / max(l_n, 1)
+        return {"lstm_kernels_avg_ms": l_avg, "vae_kernel_avg_ms": v_ms / max(v_n, 1), "steps": steps,
+                "lstm_kernels": sc1.lstm_kernels,
+                "lstm_frac_alone": executed_flop(wl, sc1.lstm_variant) / (l_avg / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS if l_n else 0.0,
+                "what": "the same call with the overlap off (one stream): each kernel's own duration"}
+    finally:
+        sc1.close()
+
+
+def side_config(name, steps, warmup, local, windows=0):
+    """One of the other BASELINE configs on this GPU, its own context and stream, inputs resident in HBM:
+    `steps` timed steps after `warmup`, HIP events around the kernels, then the kernels alone."""
+    import torch
+    from drlvae.scorer import WindowScorer
+    dev = torch.device("cuda", local)
+    wl = workload(name, 0, windows)
+    K, S = wl["K"], wl["S"]
+    stream = torch.cuda.Stream(device=dev)
+    sc = WindowScorer(local)
+    try:
+        sc.set_vae(wl["vae"])
+        sc.set_lstm(wl["lstm"])
+        sc.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            series = torch.from_numpy(wl["series"]).to(dev)
+            out = {"err": torch.empty(K, dtype=torch.float32, device=dev),
+                   "q": torch.empty((K, S, 2), dtype=torch.float32, device=dev),
+                   "action": torch.empty(K, dtype=torch.int32, device=dev),
+                   "margin": torch.empty(K, dtype=torch.float32, device=dev)}
+        stream.synchronize()
+        for _ in range(warmup):
+            sc.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
+        sc.synchronize()
+        torch.cuda.synchronize()
+        sc.profile(True)
+        sc.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sc.score_dev(series, wl["W"], wl["offsets"], out, **wl["kw"])
+        sc.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        (l_ms, l_n), (v_ms, v_n) = sc.profile_read(0), sc.profile_read(1)
+        sc.profile(False)
+        variant, overlapped = sc.lstm_variant, sc.overlapped
+        l_avg = l_ms / max(l_n, 1)
+        ex = executed_flop(wl, variant)
+        res = {"workload": wl["desc"], "value": K * steps / dt, "unit": "windows/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": dt / steps * 1e3, "timed_region_s": dt, "windows_per_step": K,
+               "flop_per_window": wl["vae_flops"] + wl["lstm_flops"], "lstm_kernel": variant, "lstm_kernels": sc.lstm_kernels,
+               "vae_kernel": sc.vae_variant, "lstm_tile": sc.lstm_tile,
+               "lstm_kernels_avg_ms": l_avg, "vae_kernel_avg_ms": v_ms / max(v_n, 1),
+               "frac": ex / (l_avg / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS if l_n else 0.0,
+               "frac_is": "flop the LSTM launch executes / its HIP-event time / 157.3 TFLOP/s",
+               "vae_and_lstm_kernels_overlap": overlapped}
+        if variant.startswith("xproj"):
+            res["algorithmic_frac"] = wl["lstm_flops"] * K / (l_avg / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS if l_n else 0.0
+        if overlapped:
+            al = kernels_alone(wl, local, stream, series, out, max(2, min(steps, 3)))
+            res["frac_alone"] = al["lstm_frac_alone"]
+            res["lstm_kernels_ms_alone"] = al["lstm_kernels_avg_ms"]
+            res["vae_kernel_ms_alone"] = al["vae_kernel_avg_ms"]
+        else:
+            res["frac_alone"] = res["frac"]
+            res["lstm_kernels_ms_alone"] = l_avg
+            res["vae_kernel_ms_alone"] = res["vae_kernel_avg_ms"]
+        # the VAE kernel against the same peak (wide windows only: there it is a real GEMM)
+        if wl["F"] > 1 and res["vae_kernel_ms_alone"] > 0:
+            res["vae_frac_alone"] = wl["vae_flops"] * K / (res["vae_kernel_ms_alone"] / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+        return res
+    finally:
+        sc.close()
+        torch.cuda.synchronize()
+
+
+def host_path(name, calls, local):
+    """The drop-in call of a numpy caller (drlvae.compat.penalty_array, WindowScorer.score): drl_score_batch
+    with pageable host buffers in and out, synchronous — PCIe included.  Never `value`."""
+    from drlvae.scorer import WindowScorer
+    wl = workload(name, 0, 0)
+    sc = WindowScorer(local)
+    try:
+        sc.set_vae(wl["vae"])
+        sc.set_lstm(wl["lstm"])
+        x, off = wl["series"], wl["offsets"]
+        for _ in range(2):
+            sc.score(x, wl["W"], off, **wl["kw"])
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            sc.score(x, wl["W"], off, **wl["kw"])
+        dt = time.perf_counter() - t0
+        return {"workload": wl["desc"], "value": wl["K"] * calls / dt, "unit": "windows/s", "calls": calls,
+                "ms_per_call": dt / calls * 1e3, "bytes_in": int(x.nbytes), "bytes_out": int(wl["K"] * (12 + 8 * wl["S"])),
+                "entry_point": "drl_score_batch: pageable numpy series in, err/q/action/margin numpy out, synchronous"}
+    finally:
+        sc.close()
+
+
+def library_info(sc):
+    """drl_version of the loaded library (it carries the hash of the sources it was compiled from) against the
+    hash of the sources in this tree: a stale prebuilt .so shows as `stale: true`."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from drlvae import _abi
+    v = sc.version
+    m = re.search(r"src ([0-9a-f]{16})", v)
+    try:
+        from src_hash import src_hash
+        tree = src_hash()
+    except Exception:
+        tree = None
+    return {"version": v, "path": os.path.relpath(_abi.LIB_PATH, ROOT), "src_hash_compiled_in": m.group(1) if m else None,
+            "src_hash_of_tree": tree, "stale": (m.group(1) != tree) if (m and tree) else None,
+            "build_mode": "prebuilt in-tree by __graft_entry__.build() (csrc/Makefile, hipcc --offload-arch=gfx950); "
+                          "nothing is compiled at run time"}
 
 
 def free_port():
@@ -277,6 +424,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the f16x3 side measurement")
+    ap.add_argument("--no-others", action="store_true",
+                    help="N = 1: skip other_configs / host_path / kernels_alone (profiling passes: one launch population per kernel)")
     ap.add_argument("--collective", default="torch", choices=["torch", "abi"],
                     help="the all-gather of the scores: torch.distributed (RCCL) or the library's own RCCL "
                          "entry point drl_allgather_scores on the scoring stream")
@@ -294,6 +443,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    default_workload = args.workload is None           # the driver's flag-less run: it also carries the other configs
     if args.workload is None:
         args.workload = "c2" if world == 1 else "c5"
     if args.shard and args.workload != "c4":
@@ -301,18 +451,43 @@ def main():
     # rehearsal of the N>1 path on a one-GPU box: DRLVAE_BENCH_REHEARSE=1 puts every rank on cuda:0 and
     # swaps RCCL (which refuses two ranks on one device) for gloo.  Never a measurement.
     rehearse = os.environ.get("DRLVAE_BENCH_REHEARSE") == "1"
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if rehearse:
         local = 0
-    else:
-        local %= max(1, torch.cuda.device_count())        # a launcher may expose one device per rank
+    elif ndev >= local_world:
+        pass                                              # one visible device per local rank: rank i on device i
+    elif ndev == 1 and world > 1:
+        local = 0                                         # a launcher that masks the devices per rank; checked below
+    elif ndev < local_world:
+        raise SystemExit(f"bench.py: {local_world} ranks on this node but {ndev} visible GPU(s): refusing to put two "
+                         f"ranks on one device (DRLVAE_BENCH_REHEARSE=1 rehearses the N>1 path on one GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if rehearse else dev  # gloo has no GPU all_gather: the rehearsal stages through the host
+    rccl_ranks, devices = 1, None
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # which physical device each rank sits on: N ranks must be on N different GPUs (a per-rank device mask
+        # that maps two ranks to one GPU would otherwise go unnoticed)
+        pr = torch.cuda.get_device_properties(local)
+        ident = str(getattr(pr, "uuid", "")) or str(getattr(pr, "pci_bus_id", ""))
+        ident = f"{socket.gethostname()}:{ident}:{getattr(pr, 'pci_bus_id', '')}:{getattr(pr, 'pci_device_id', '')}"
+        devices = [None] * world
+        dist.all_gather_object(devices, ident)
+        if not rehearse and len(set(devices)) != world:
+            raise SystemExit(f"bench.py: {world} ranks share {len(set(devices))} device(s) {sorted(set(devices))}: "
+                             f"every rank needs a GPU of its own")
+        # ranks as the collective library itself counts them: a device-side sum of ones over the group
+        # (backend "nccl" = RCCL; in the rehearsal gloo on the host)
+        ones = torch.ones(1, dtype=torch.float32, device=cdev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(round(float(ones.item())))
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: the all-reduce over the process group counted {rccl_ranks} ranks, expected {world}")
 
     if args.workload == "c5" and not args.windows:
         args.windows = 4e6
@@ -349,10 +524,14 @@ def main():
     stream.synchronize()
 
     use_abi = gather and args.collective == "abi" and not rehearse
+    abi_ranks = None
     if use_abi:
         ids = [sc.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         sc.comm_init(rank, world, ids[0])
+        abi_ranks = sc.comm_size()                        # ncclCommCount of the library's own communicator
+        if abi_ranks != world:
+            raise SystemExit(f"bench.py: drl_comm_size reports {abi_ranks} ranks, expected {world}")
 
     pending = [None] * nbuf
     counter = [0]
@@ -409,36 +588,16 @@ def main():
         step()
     dt, ((lstm_ms, lstm_n), (vae_ms, vae_n)) = timed(args.steps)
     variant = sc.lstm_variant  # of the headline run (the alt run below changes it)
+    lstm_kernel_names = sc.lstm_kernels
+    vae_variant = sc.vae_variant
     overlapped = sc.overlapped
 
     # When the VAE kernel ran on the second stream beside the LSTM kernels, the per-kernel durations above share
     # one time span.  A few untimed steps on a second context with the overlap off give each kernel's own duration
     # (reported beside the roofline line, never as `value`).
     alone = None
-    if overlapped and rank == 0:
-        os.environ["DRLVAE_OVERLAP"] = "0"
-        try:
-            sc1 = WindowScorer(local)
-        finally:
-            del os.environ["DRLVAE_OVERLAP"]
-        try:
-            sc1.set_vae(wl["vae"])
-            sc1.set_lstm(wl["lstm"])
-            sc1.set_stream(stream.cuda_stream)
-            n1 = max(2, min(args.steps, 5))
-            for _ in range(2):
-                sc1.score_dev(series, wl["W"], wl["offsets"], outs[0], **wl["kw"])
-            sc1.synchronize()
-            sc1.profile(True)
-            sc1.profile_reset()
-            for _ in range(n1):
-                sc1.score_dev(series, wl["W"], wl["offsets"], outs[0], **wl["kw"])
-            sc1.synchronize()
-            (l_ms, l_n), (v_ms, v_n) = sc1.profile_read(0), sc1.profile_read(1)
-            alone = {"lstm_kernels_avg_ms": l_ms / max(l_n, 1), "vae_kernel_avg_ms": v_ms / max(v_n, 1), "steps": n1,
-                     "what": "the same call with DRLVAE_OVERLAP=0 (one stream): each kernel's own duration"}
-        finally:
-            sc1.close()
+    if overlapped and rank == 0 and not args.no_others:
+        alone = kernels_alone(wl, local, stream, series, outs[0], max(2, min(args.steps, 5)))
         torch.cuda.synchronize()
 
     # the rate of ONE GPU on this same workload with the collective off (rank 0's own kernels, same steps):
@@ -470,12 +629,9 @@ def main():
     if rank == 0:
         total_windows = K_total * args.steps
         lstm_avg_s = lstm_ms / max(lstm_n, 1) / 1e3
-        Hh, Ff, Ww = wl["H"], wl["F"], wl["W"]
-        n_samples = int(wl["series"].shape[0])
         algorithmic = wl["lstm_flops"] * K
         # what the launch really executes: the xproj paths project each SAMPLE once, not each window's W rows
-        executed = (n_samples * 2 * Ff * 4 * Hh + K * S * (Ww * 2 * Hh * 4 * Hh + 2 * Hh * 2)
-                    if variant.startswith("xproj") else algorithmic)
+        executed = executed_flop(wl, variant)
         achieved = executed / lstm_avg_s / 1e12 if lstm_n else 0.0
         res = {
             "metric": "windows scored/sec (VAE reward + LSTM Q)",
@@ -492,18 +648,23 @@ def main():
             "data": wl["data"],
             "config": {"workload": wl["desc"], "windows_per_gpu_per_step": K, "windows_per_rank": ks,
                        "windows_per_step_all_gpus": K_total, "ranks": world,
-                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                       "rccl_ranks": rccl_ranks,
+                       "rccl_ranks_is": ("a device-side all_reduce of ones over the nccl (= RCCL) process group"
+                                         if world > 1 and not rehearse else
+                                         "REHEARSAL: an all_reduce of ones over gloo on the host" if world > 1 else "single process"),
+                       "abi_comm_ranks": abi_ranks, "devices": devices,
                        "window": wl["W"], "features": wl["F"], "hidden": wl["H"], "candidate_states": S,
                        "flop_per_window": wl["vae_flops"] + wl["lstm_flops"],
                        "collective": ("none" if not gather else "gloo all_gather (REHEARSAL, not a measurement)"
                                       if rehearse else ("one rccl all_gather (drl_allgather_scores) of the packed err/q/action/margin block per step"
                                                        if use_abi else "one rccl all_gather of the packed err/q/action/margin block per step, overlapped with the next step's kernels")),
-                       "lstm_kernel": variant,
+                       "lstm_kernel": variant, "lstm_kernels": lstm_kernel_names, "vae_kernel": vae_variant,
                        "vae_and_lstm_kernels_overlap": overlapped},
             "roofline": {"bound": "mfma", "kernel": "lstm_" + variant,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(wl["name"], variant),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(wl["name"], lstm_kernel_names),
+                         "traffic_unit": "HBM-side bytes per scoring call of exactly config.lstm_kernels (rocprofv3 FETCH_SIZE x2 "
+                                         "gfx950 correction + WRITE_SIZE, per-launch averages of the committed PMC summary)",
                          "algorithmic_bytes_per_launch": (4 * wl["F"] + 4 + 4 * 2 * S + 4) * K,
                          "avg_launch_ms": lstm_avg_s * 1e3, "launches": lstm_n,
                          "flop_per_launch": executed,
@@ -519,7 +680,6 @@ def main():
                                        "vae_kernel_avg_ms are the spans of kernels that share the CUs with each other; "
                                        "kernels_alone holds each kernel's own duration (a few steps on one stream)")
             if alone is not None:
-                alone["lstm_frac_alone"] = executed / (alone["lstm_kernels_avg_ms"] / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS
                 res["roofline"]["kernels_alone"] = alone
         tr = res["roofline"]["traffic"]
         if tr and lstm_avg_s > 0:
@@ -530,6 +690,13 @@ def main():
             res["single_gpu_same_workload"] = single
         if alt is not None:
             res["alt_arithmetic"] = alt
+        res["library"] = library_info(sc)
+        if world == 1 and default_workload and not args.no_others:
+            # every other BASELINE config, and the host-pointer drop-in path, observed in this same run
+            plan = {"c5": (5, 1, 4e6), "c3": (40, 5, 0), "c4": (8, 2, 0), "c1": (300, 20, 0), "c2": (20, 3, 0)}
+            res["other_configs"] = [side_config(n, *plan[n][:2], local, plan[n][2])
+                                    for n in ("c5", "c3", "c4", "c1", "c2") if n != wl["name"]]
+            res["host_path"] = [host_path(n, c, local) for n, c in (("c2", 20), ("c4", 10))]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(res), flush=True)

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -40,6 +41,12 @@ unsigned char* g_scratch_dev[MAX_DEVICES] = {};   // device address of `scratch`
 std::mutex g_scratch_mu;
 
 thread_local std::string g_create_error = "";
+
+// Every site in this library that makes the HIP runtime allocate something — device memory, pinned host
+// memory, an event, a stream, an RCCL communicator — bumps this counter (drl_debug_alloc_count): the test
+// of the entry point that allocates nothing asserts that it does not move across a call.
+std::atomic<long long> g_alloc_count{0};
+inline void count_alloc() { g_alloc_count.fetch_add(1, std::memory_order_relaxed); }
 
 struct DevBuf {
     void* p = nullptr;
@@ -109,6 +116,16 @@ struct drl_ctx {
     const int* tl_dev = nullptr;  // set by drl_rollout_batch around a sparse pass: the 16-window tiles score_impl works on
     int tl_n = 0;
     int rec2_mode = 1;            // two candidate states in one wave: 0 never, 1 whole rounds of tiles, 2 always (DRLVAE_REC2)
+    // test and measurement knobs (drl_set_knob; the environment variables DRLVAE_<NAME> are read ONCE, at
+    // drl_create — no getenv on any call path)
+    long long vw16_pad = 0;       // extra LDS bytes per vae_wide16 workgroup: fewer workgroups per CU
+    long long rec_lds_pad = 0;    // the same for lstm_rec / lstm_rec2
+    long long pbuf_max = -1;      // >= 0: behave as if a projection buffer above this many bytes could not be had
+    long long pipe_min = 0;       // > 0: host inputs of at least this many bytes are pipelined (default 16 MiB)
+    long long pipe_chunk = 0;     // > 0: fixed chunk size of the pipelined host path, in samples
+    bool no_pipeline = false;     // host path: always the one-shot copy
+    bool no_fused_epilogue = false;   // action / margin always by finalize_kernel
+    bool rollout_dense = false;   // drl_rollout_batch: full passes only
     bool last_overlap = false;
     std::string err;
     VaeHost vae;
@@ -135,6 +152,7 @@ struct drl_ctx {
     size_t pin_io_cap = 0;
     Prof prof;
     const char* last_variant = "none";
+    std::string last_kernels;   // the LSTM kernels the last scoring call launched, as rocprofv3 names them, ';'-separated
     int last_tile = 0;   // windows per workgroup tile of the last LSTM launch (0: not a tiled kernel)
     const char* last_vae_variant = "none";
     size_t wide_lds_set = 0, gemv_lds_set = 0;
@@ -151,7 +169,8 @@ struct drl_ctx {
         long long K = 0;
         int t32 = 0, t64 = 0, t16 = 0;
         hipEvent_t ev = nullptr;
-        bool busy = false;
+        bool busy = false;      // ev marks the last kernels that read the slot
+        bool ever = false;      // the slot has been handed out before (a fresh slot has no reader to wait for)
     };
     static constexpr int SEG_SLOTS = 4;
     SegSlot seg_slots[SEG_SLOTS];
@@ -186,6 +205,7 @@ int ensure(drl_ctx* c, DevBuf& b, size_t bytes) {
     // the new block first: a failed grow leaves the old one (and whatever it holds) in place
     size_t cap = std::max<size_t>(bytes, 256);
     void* np = nullptr;
+    count_alloc();
     HIP_TRY(c, hipMalloc(&np, cap));
     if (b.p) (void)hipFree(b.p);
     b.p = np;
@@ -197,6 +217,7 @@ int ensure_pin_io(drl_ctx* c, size_t bytes) {
     if (bytes <= c->pin_io_cap) return DRL_OK;
     if (c->pin_io) { HIP_TRY(c, hipHostFree(c->pin_io)); c->pin_io = nullptr; c->pin_io_cap = 0; }
     size_t cap = std::max<size_t>(bytes, 64 * 1024);
+    count_alloc();
     HIP_TRY(c, hipHostMalloc(&c->pin_io, cap, hipHostMallocDefault));
     c->pin_io_cap = cap;
     return DRL_OK;
@@ -243,7 +264,7 @@ void prof_begin(drl_ctx* c, int which, hipStream_t st, bool chain = false) {
     for (hipEvent_t* e : {&p.a, &p.b}) {
         if (e == &p.a && p.a_shared) { p.a = c->prof.pending.back().b; continue; }
         if (!c->prof.pool.empty()) { *e = c->prof.pool.back(); c->prof.pool.pop_back(); }
-        else if (hipEventCreate(e) != hipSuccess) { *e = nullptr; }
+        else { count_alloc(); if (hipEventCreate(e) != hipSuccess) *e = nullptr; }
     }
     p.which = which;
     if (p.a && !p.a_shared) (void)hipEventRecord(p.a, st);
@@ -349,11 +370,15 @@ int build_segments(drl_ctx* c, const int64_t* seg_offsets, int n_seg, int W, boo
     sl.key.clear();
     // kernels of an earlier asynchronous call may still read this slot, and its pinned block may still be
     // the source of that call's copy: both are behind the slot's event
+    // (a slot never handed out before has neither: the first pipelined call after drl_create overlaps from
+    // its first chunk)
     if (sl.busy) { HIP_TRY(c, hipEventSynchronize(sl.ev)); sl.busy = false; }
-    else HIP_TRY(c, hipStreamSynchronize(c->stream));      // a user that recorded nothing (synchronous entry points: a no-op)
+    else if (sl.ever) HIP_TRY(c, hipStreamSynchronize(c->stream));      // a user that recorded nothing (synchronous entry points: a no-op)
+    sl.ever = true;
     if (bytes > sl.pinned_cap) {
         if (sl.pinned) { HIP_TRY(c, hipHostFree(sl.pinned)); sl.pinned = nullptr; sl.pinned_cap = 0; }
         const size_t cap = std::max<size_t>(bytes * 2, 4096);
+        count_alloc();
         HIP_TRY(c, hipHostMalloc(&sl.pinned, cap, hipHostMallocDefault));
         sl.pinned_cap = cap;
     }
@@ -437,7 +462,14 @@ void fill_lstm_args(drl_ctx* c, LstmArgs& a) {
 // =================================================================================================
 extern "C" {
 
-const char* drl_version(void) { return "drlvae 0.1 (gfx950)"; }
+// DRL_SRC_HASH: sha256 (first 16 hex digits) over the library's sources, passed in by csrc/Makefile; bench.py
+// and tests/test_abi.py compare it with the hash of the tree they run from, so a stale prebuilt library shows.
+#ifndef DRL_SRC_HASH
+#define DRL_SRC_HASH "unknown"
+#endif
+#define DRL_STR2(x) #x
+#define DRL_STR(x) DRL_STR2(x)
+const char* drl_version(void) { return "drlvae 0.3 (gfx950; abi " DRL_STR(DRL_ABI_REVISION) "; src " DRL_SRC_HASH ")"; }
 
 int drl_create(int device_id, drl_ctx** out) {
     if (!out) return fail(nullptr, DRL_ERR_ARG, "drl_create: out is NULL");
@@ -460,6 +492,7 @@ int drl_create(int device_id, drl_ctx** out) {
     drl_ctx* c = new drl_ctx();
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    count_alloc();      // set-up: streams, events, the pinned staging block below
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
@@ -510,11 +543,37 @@ int drl_create(int device_id, drl_ctx** out) {
         if (c->na_stage) { (void)hipHostFree(c->na_stage); c->na_stage = nullptr; }
         c->scratch_dev = nullptr;               // drl_score_batch_dev_noalloc reports DRL_ERR_STATE
     }
-    if (const char* e = getenv("DRLVAE_FORCE_GENERIC")) c->force_generic = atoi(e) != 0;
-    if (const char* e = getenv("DRLVAE_OVERLAP")) if (c->aux_stream) c->overlap_mode = atoi(e);
-    if (const char* e = getenv("DRLVAE_REC2")) c->rec2_mode = atoi(e);
-    if (const char* e = getenv("DRLVAE_ROLLOUT")) c->rollout_mode = std::min(2, std::max(0, atoi(e)));
-    if (const char* e = getenv("DRLVAE_GEMV_ROUNDS")) c->gemv_rounds = std::max(0, atoi(e));
+    // Dynamic-LDS limits of every kernel that asks for more than 64 KiB, once per context (= per device) here, so
+    // that no scoring call — the one that allocates nothing included — changes a function attribute on its first
+    // use.  Should one of them fail, the launch sites still set theirs lazily and report the error there.
+    {
+        auto attr = [](const void* f, size_t bytes) {
+            return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+        };
+        const bool ok =
+            attr(reinterpret_cast<const void*>(vae_kernel<2, true>), CHAIN_LDS_MAX) &&
+            attr(reinterpret_cast<const void*>(vae_kernel<DRL_VAE_MAX_TILES, true>), CHAIN_LDS_MAX) &&
+            attr(reinterpret_cast<const void*>(vae_wide16_kernel<true>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16_kernel<false>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(lstm_rec2_kernel<8>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(lstm_gemv_kernel<8>), 150 * 1024) &&
+            attr(reinterpret_cast<const void*>(lstm_gemv_kernel<16>), 150 * 1024) &&
+            attr(reinterpret_cast<const void*>(rollout_seq_kernel<8>), 150 * 1024) &&
+            attr(reinterpret_cast<const void*>(rollout_seq_kernel<16>), 150 * 1024);
+        if (ok) {
+            c->chain_lds_set = true; c->rec_attr_set = true;
+            c->wide_lds_set = 160 * 1024; c->gemv_lds_set = 150 * 1024; c->rollout_lds_set = 150 * 1024;
+        } else (void)hipGetLastError();
+    }
+    // the environment is read here and nowhere else
+    for (const char* name : {"force_generic", "overlap", "rec2", "rollout", "gemv_rounds", "vw16_pad", "rec_lds_pad", "pbuf_max",
+                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense"}) {
+        std::string var = "DRLVAE_";
+        for (const char* p = name; *p; ++p) var += (char)toupper((unsigned char)*p);
+        if (const char* e = getenv(var.c_str())) (void)drl_set_knob(c, name, atoll(e));
+    }
     *out = c;
     return DRL_OK;
 }
@@ -573,6 +632,28 @@ int drl_set_rollout_mode(drl_ctx* c, int mode) {
     c->rollout_mode = mode;
     return DRL_OK;
 }
+
+int drl_set_knob(drl_ctx* c, const char* name, long long v) {
+    if (!c || !name) return DRL_ERR_ARG;
+    const std::string n = name;
+    if (n == "force_generic") c->force_generic = v != 0;
+    else if (n == "overlap") { if (c->aux_stream) c->overlap_mode = (int)std::min<long long>(2, std::max<long long>(0, v)); }
+    else if (n == "rec2") c->rec2_mode = (int)std::min<long long>(2, std::max<long long>(0, v));
+    else if (n == "rollout") c->rollout_mode = (int)std::min<long long>(2, std::max<long long>(0, v));
+    else if (n == "gemv_rounds") c->gemv_rounds = (int)std::max<long long>(-1, v);
+    else if (n == "vw16_pad") c->vw16_pad = std::max<long long>(0, v);
+    else if (n == "rec_lds_pad") c->rec_lds_pad = std::max<long long>(0, v);
+    else if (n == "pbuf_max") c->pbuf_max = v;
+    else if (n == "pipe_min") c->pipe_min = std::max<long long>(0, v);
+    else if (n == "pipe_chunk") c->pipe_chunk = std::max<long long>(0, v);
+    else if (n == "no_pipeline") c->no_pipeline = v != 0;
+    else if (n == "no_fused_epilogue") c->no_fused_epilogue = v != 0;
+    else if (n == "rollout_dense") c->rollout_dense = v != 0;
+    else return fail(c, DRL_ERR_ARG, "drl_set_knob: unknown knob '%s'", name);
+    return DRL_OK;
+}
+
+long long drl_debug_alloc_count(void) { return g_alloc_count.load(std::memory_order_relaxed); }
 
 int drl_synchronize(drl_ctx* c) {
     if (!c) return DRL_ERR_ARG;
@@ -953,6 +1034,10 @@ int check_opts(drl_ctx* c, const drl_score_opts* o, int F) {
     if (!o) return fail(c, DRL_ERR_ARG, "opts is NULL");
     if (o->struct_size != (int32_t)sizeof(drl_score_opts))
         return fail(c, DRL_ERR_ARG, "opts.struct_size %d != %zu", o->struct_size, sizeof(drl_score_opts));
+    // revision 2: vae_center / vae_scale are const double* (revision 1, which left this field 0: const float*)
+    if (o->abi_revision != DRL_ABI_REVISION)
+        return fail(c, DRL_ERR_ARG, "opts.abi_revision %d: this library speaks revision %d of drl_score_opts "
+                    "(set it to DRL_ABI_REVISION from the header you compile against)", o->abi_revision, DRL_ABI_REVISION);
     if (o->vae_lag != 0 && o->vae_lag != 1) return fail(c, DRL_ERR_ARG, "opts.vae_lag must be 0 or 1");
     if (o->flag_mode < 0 || o->flag_mode > 3) return fail(c, DRL_ERR_ARG, "opts.flag_mode %d", o->flag_mode);
     if (o->action_rule < 0 || o->action_rule > 1) return fail(c, DRL_ERR_ARG, "opts.action_rule %d", o->action_rule);
@@ -992,6 +1077,13 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
     SegHost sh;
     OptDev od;
     int rc;
+    // Whatever path leaves this function after kernels may have been queued (an error after a launch included),
+    // the table slot's event is recorded behind them: an eviction of the slot then waits for THOSE kernels, not
+    // for an older call's.
+    struct SlotGuard {
+        drl_ctx* c; bool on;
+        ~SlotGuard() { if (on && seg_mark(c) != DRL_OK) (void)hipGetLastError(); }
+    } guard{c, false};
     if (noalloc) {
         c->seg_last = -1;
         if ((rc = noalloc_tables(c, seg_offsets, n_seg, W, o, W * F, sh, od))) return rc;
@@ -1001,6 +1093,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         if ((rc = build_segments(c, seg_offsets, n_seg, W, false, sh))) return rc;
         if (K_out) *K_out = sh.K_total;
         if (sh.K_total == 0) return DRL_OK;
+        guard.on = true;
         if (od_pre) od = *od_pre;
         else if ((rc = upload_opts(c, o, n_seg, W * F, od))) return rc;
     }
@@ -1015,8 +1108,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             *P = (float*)(c->scratch_dev + DRL_SCRATCH_P_OFFSET);
             return DRL_OK;
         }
-        if (const char* e = getenv("DRLVAE_PBUF_MAX"))       // tests: behave as if a larger allocation had failed
-            if (bytes > (size_t)atoll(e)) return fail(c, DRL_ERR_HIP, "projections: %zu bytes over DRLVAE_PBUF_MAX", bytes);
+        if (c->pbuf_max >= 0 && bytes > (size_t)c->pbuf_max)       // tests: behave as if a larger allocation had failed
+            return fail(c, DRL_ERR_HIP, "projections: %zu bytes over the pbuf_max knob", bytes);
         int r = ensure(c, c->pbuf, bytes);
         if (r) return r;
         *P = (float*)c->pbuf.p;
@@ -1038,7 +1131,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         // wide windows: stream the first/last layer through LDS when the workgroup's flat region fits
         const int xr_floats = (63 * F + ((W * F + 31) & ~31) + 3) & ~3;
         size_t wide_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
-        if (const char* e = getenv("DRLVAE_VW16_PAD")) wide_lds = std::min<size_t>(wide_lds + (size_t)atoi(e), 160 * 1024);   // measurement knob: fewer workgroups per CU
+        if (c->vw16_pad) wide_lds = std::min<size_t>(wide_lds + (size_t)c->vw16_pad, 160 * 1024);   // measurement knob: fewer workgroups per CU
         const bool wide = c->vae.wide16 && !d_eps && wide_lds <= 160 * 1024;
         if (prof) prof_begin(c, 1, vst);
         if (wide) {
@@ -1102,7 +1195,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         // argmax epilogue inside the LSTM kernel whenever the workgroup that computes a window's Q holds every
         // value the rule needs: one candidate state, or both candidates in one wave (lstm_rec2_kernel for
         // every tile).  Otherwise finalize_kernel below.  DRLVAE_NO_FUSED_EPILOGUE=1: always finalize_kernel (tests).
-        bool fused_epilogue = (d_action || d_margin) && a.S == 1 && getenv("DRLVAE_NO_FUSED_EPILOGUE") == nullptr;
+        bool fused_epilogue = (d_action || d_margin) && a.S == 1 && !c->no_fused_epilogue;
         if (fused_epilogue) { a.action = d_action; a.margin = d_margin; a.rule = o->action_rule; }
         // hidden widths 65..128 are packed zero-padded to 16 gate tiles x 64 k-steps (padded units stay at h = 0)
         const bool fast = c->lstm.I == 2 && c->lstm.NT == 16 && F == 1 && W >= 2 && W + 65 <= H128_SV;
@@ -1121,6 +1214,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             }
         }
         c->last_tile = 0;
+        c->last_kernels.clear();
+        auto ran = [&](const char* name) { if (!c->last_kernels.empty()) c->last_kernels += ';'; c->last_kernels += name; };
         if (prof) prof_begin(c, 0, c->stream, want_vae && !overlap);   // serial: the VAE kernel's end event is the start
         if (fast && c->tl_n > 0 && c->lstm.has16) {
             // a sparse pass of the rollout's fixed point: only the listed 16-window tiles
@@ -1132,6 +1227,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
             // more tiles than CUs: a workgroup walks several (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(std::min(c->tl_n, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
+            ran("lstm_h128i2_w16_kernel");
             c->last_variant = "h128i2"; c->last_tile = 16;
         } else if (fast && c->lstm_math == 1 && c->lstm.has_split) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
@@ -1140,6 +1236,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.uhi = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.uhi_off);
             fa.ulo = reinterpret_cast<const u32x4*>((const float*)c->lstm_w.p + c->lstm.ulo_off);
             hipLaunchKernelGGL(lstm_h128i2_f16x3_kernel, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, fa);
+            ran("lstm_h128i2_f16x3_kernel");
             c->last_variant = "h128i2_f16x3"; c->last_tile = 64;
         } else if (fast && c->lstm.has16 && sh.tiles16 * a.S <= c->n_cu) {
             // a call of a few thousand windows (one series): 16-window tiles, twice as many workgroups again
@@ -1150,16 +1247,19 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             fa.wx16 = (const float*)c->lstm_w.p + c->lstm.wx16_off;
             fa.bias16 = (const float*)c->lstm_w.p + c->lstm.bias16_off;
             hipLaunchKernelGGL(lstm_h128i2_w16_kernel, dim3(sh.tiles16, a.S), dim3(256), 0, c->stream, fa);
+            ran("lstm_h128i2_w16_kernel");
             c->last_variant = "h128i2"; c->last_tile = 16;
         } else if (fast && sh.tiles32 <= c->n_cu) {
             // a small call (one series, a replay batch): 32-window tiles over twice as many CUs
             a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
             hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, a);
+            ran("lstm_h128i2_kernel<1>");
             c->last_variant = "h128i2"; c->last_tile = 32;
         } else if (fast) {
             a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
             // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
             hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
+            ran("lstm_h128i2_kernel<2>");
             c->last_variant = "h128i2"; c->last_tile = 64;
         } else if (c->lstm.NT == 16 && use_proj) {
             // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
@@ -1170,6 +1270,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             xa.P = Pbuf; xa.nt_total = 16;
             xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128), 2), dim3(256), 0, c->stream, xa);
+            ran("xproj_kernel<8>");
             RecArgs ra;
             ra.P = xa.P; ra.n_samples = n_samples; ra.win_rows = 1;
             ra.flagw = (const float*)c->lstm_w.p + c->lstm.flagw_off;
@@ -1177,18 +1278,20 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
                 ra.l = a;
                 hipLaunchKernelGGL(lstm_h128p_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, ra);
+                ran("lstm_h128p_kernel<1>");
             } else {
                 a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
                 ra.l = a;
                 const unsigned gx = std::min<unsigned>(sh.tiles64, std::max(1, c->n_cu / a.S));
                 hipLaunchKernelGGL(lstm_h128p_kernel<2>, dim3(gx, a.S), dim3(256), 0, c->stream, ra);
+                ran("lstm_h128p_kernel<2>");
             }
             c->last_variant = "xproj+h128";
         } else if (c->lstm.NT == 8 && use_proj) {
             // H <= 64: project every sample once, then run the recurrences from the projections (a chunk of P stays < 4 GiB)
             const long long n_samples = seg_offsets[n_seg];
             size_t lds = ((size_t)32 * 8 * 64 + 8 * 32) * sizeof(float);   // U + the flag row
-            if (const char* e = getenv("DRLVAE_REC_LDS_PAD")) lds = std::min<size_t>(lds + (size_t)atoi(e), 160 * 1024);   // measurement knob: workgroups per CU
+            if (c->rec_lds_pad) lds = std::min<size_t>(lds + (size_t)c->rec_lds_pad, 160 * 1024);   // measurement knob: workgroups per CU
             if (!c->rec_attr_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1203,6 +1306,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             xa.P = Pbuf; xa.nt_total = 8;
             xa.samp_off = sh.d_samp; xa.n_seg = n_seg; xa.in_scale = od.in_scale; xa.in_offset = od.in_offset;
             hipLaunchKernelGGL(xproj_kernel<8>, dim3((unsigned)((n_samples + 127) / 128)), dim3(256), 0, c->stream, xa);
+            ran("xproj_kernel<8>");
             RecArgs ra;
             a.n_tiles = sh.tiles32;
             ra.l = a; ra.P = xa.P; ra.n_samples = n_samples; ra.win_rows = 1;
@@ -1223,26 +1327,34 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 const int n2 = c->rec2_mode == 0 ? 0 : c->rec2_mode == 2 ? sh.tiles32
                                : overlap ? 0
                                : 2 * rem <= slots ? sh.tiles32 - rem : sh.tiles32;
-                if (n2 == sh.tiles32 && (d_action || d_margin) && getenv("DRLVAE_NO_FUSED_EPILOGUE") == nullptr) {
+                if (n2 == sh.tiles32 && (d_action || d_margin) && !c->no_fused_epilogue) {
                     fused_epilogue = true;
                     ra.l.action = d_action; ra.l.margin = d_margin; ra.l.rule = o->action_rule;
                 }
                 if (n2 > 0) {
                     ra.l.n_tiles = n2; ra.tile0 = 0;
                     hipLaunchKernelGGL(lstm_rec2_kernel<8>, dim3((n2 + 3) / 4), dim3(256), lds, c->stream, ra);
+                    ran("lstm_rec2_kernel<8>");
                 }
                 if (n2 < sh.tiles32) {
                     ra.l.n_tiles = sh.tiles32; ra.tile0 = n2;
                     hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3((sh.tiles32 - n2 + 1) / 2), dim3(256), lds, c->stream, ra);
+                    ran("lstm_rec_kernel<8, true>");
                 }
-            } else if (a.flag_mode > 0) hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
-            else hipLaunchKernelGGL((lstm_rec_kernel<8, false>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
+            } else if (a.flag_mode > 0) {
+                hipLaunchKernelGGL((lstm_rec_kernel<8, true>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
+                ran("lstm_rec_kernel<8, true>");
+            } else {
+                hipLaunchKernelGGL((lstm_rec_kernel<8, false>), dim3(rec_grid), dim3(256), lds, c->stream, ra);
+                ran("lstm_rec_kernel<8, false>");
+            }
             c->last_variant = "xproj+rec";
         } else {
             a.n_tiles = sh.tiles32;
             const dim3 grid((sh.tiles32 + 3) / 4, a.S);
             if (c->lstm.NT == 8) hipLaunchKernelGGL(lstm_generic_kernel<8>, grid, dim3(256), 0, c->stream, a);
             else hipLaunchKernelGGL(lstm_generic_kernel<16>, grid, dim3(256), 0, c->stream, a);
+            ran(c->lstm.NT == 8 ? "lstm_generic_kernel<8>" : "lstm_generic_kernel<16>");
             c->last_variant = "generic";
         }
         if (prof) prof_end(c, c->stream);
@@ -1260,7 +1372,9 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             HIP_TRY(c, hipGetLastError());
         }
     }
-    return noalloc ? DRL_OK : seg_mark(c);
+    if (noalloc) return DRL_OK;
+    guard.on = false;
+    return seg_mark(c);
 }
 
 long long count_windows(const int64_t* seg_offsets, int n_seg, int W) {
@@ -1356,8 +1470,8 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
     const size_t in_bytes = (size_t)total * F * sizeof(float);
     size_t PIPE_MIN = (size_t)16 << 20;
     const size_t CHUNK = (size_t)8 << 20;
-    if (const char* e = getenv("DRLVAE_PIPE_MIN")) if (atoll(e) > 0) PIPE_MIN = (size_t)atoll(e);   // tests: pipeline small inputs too
-    const bool pipelined = in_bytes >= PIPE_MIN && c->copy_stream && c->copy_ev[0] && getenv("DRLVAE_NO_PIPELINE") == nullptr;
+    if (c->pipe_min > 0) PIPE_MIN = (size_t)c->pipe_min;   // tests: pipeline small inputs too
+    const bool pipelined = in_bytes >= PIPE_MIN && c->copy_stream && c->copy_ev[0] && !c->no_pipeline;
     if (!pipelined) {
         HIP_TRY(c, hipMemcpyAsync(d_in, series, in_bytes, hipMemcpyHostToDevice, c->stream));
         if (explicit_flags)
@@ -1375,8 +1489,8 @@ int drl_score_batch(drl_ctx* c, const float* series, const int64_t* seg_offsets,
         // kernels' time plus that first copy, not plus the whole upload (C4: 8.9 -> 7.0 ms, tools/host_path_rate.py).
         long long chunk_samples = std::max<long long>((long long)(CHUNK / (F * sizeof(float))), 4 * (long long)W);
         long long chunk_cap = std::max<long long>(chunk_samples, 32768 + (long long)W);
-        if (const char* e = getenv("DRLVAE_PIPE_CHUNK"))          // tests, tuning: fixed chunk size in samples
-            if (atoll(e) > 0) chunk_samples = chunk_cap = std::max<long long>(atoll(e), 4 * (long long)W);
+        if (c->pipe_chunk > 0)                                    // tests, tuning: fixed chunk size in samples
+            chunk_samples = chunk_cap = std::max<long long>(c->pipe_chunk, 4 * (long long)W);
         const bool may_cut = o->flag_mode != DRL_FLAG_QUIRK;
         long long copied = 0;                            // samples [0, copied) are on the device or on their way
         long long win_done = 0;                          // windows of the chunks before this one
@@ -1707,7 +1821,7 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
         if (in_scale) {
             drl_score_opts oo;
             memset(&oo, 0, sizeof oo);
-            oo.in_scale = in_scale; oo.in_offset = in_offset;
+            oo.in_scale = in_scale; oo.in_offset = in_offset; oo.abi_revision = DRL_ABI_REVISION;
             if ((rc = upload_opts(c, &oo, n_seg, W, od))) return rc;
         }
         RolloutSeqArgs ra;
@@ -1737,7 +1851,7 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
     if (c->rollout_mode == 2) return run_sequential();     // *passes_out stays 0: no parallel passes were made
     drl_score_opts o;
     memset(&o, 0, sizeof o);
-    o.struct_size = sizeof o; o.vae_lag = 1; o.flag_mode = DRL_FLAG_EXPLICIT; o.action_rule = DRL_ACTION_ARGMAX;
+    o.struct_size = sizeof o; o.abi_revision = DRL_ABI_REVISION; o.vae_lag = 1; o.flag_mode = DRL_FLAG_EXPLICIT; o.action_rule = DRL_ACTION_ARGMAX;
     o.flags = (const float*)c->st_flags.p;
     o.in_scale = in_scale; o.in_offset = in_offset;
     SegHost sh;
@@ -1748,7 +1862,7 @@ int drl_rollout_batch(drl_ctx* c, const float* series, const int64_t* seg_offset
     // pass costs one latency-bound launch over a few tiles instead of a scoring call of the whole batch (all 67
     // A1 series: 33 passes, 81 -> 9 ms).  Needs the register-stationary fp32 kernel family (16-window tiles).
     const bool sparse_ok = c->lstm.I == 2 && c->lstm.NT == 16 && c->lstm.has16 && c->lstm_math == 0 &&
-                           W + 65 <= H128_SV && getenv("DRLVAE_ROLLOUT_DENSE") == nullptr;
+                           W + 65 <= H128_SV && !c->rollout_dense;
     const size_t ctl_bytes = 256;                                      // ctl[0] = changed, ctl[1] = tiles listed
     if ((rc = ensure(c, c->st_margin, ctl_bytes + (sparse_ok ? (size_t)2 * sh.tiles16 * sizeof(int) : 0)))) return rc;
     SegTab seg;
@@ -1890,6 +2004,8 @@ int drl_profile_read(drl_ctx* c, int which, double* total_ms, int64_t* launches)
     return DRL_OK;
 }
 const char* drl_last_lstm_variant(drl_ctx* c) { return c ? c->last_variant : "none"; }
+const char* drl_last_vae_variant(drl_ctx* c) { return c ? c->last_vae_variant : "none"; }
+const char* drl_last_lstm_kernels(drl_ctx* c) { return c ? c->last_kernels.c_str() : ""; }
 int drl_last_lstm_tile(drl_ctx* c) { return c ? c->last_tile : 0; }
 int drl_last_call_overlapped(drl_ctx* c) { return c && c->last_overlap ? 1 : 0; }
 
@@ -1900,6 +2016,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -1913,10 +2030,11 @@ int rccl_load(drl_ctx* c) {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.GetErrorString) {
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy || !g_rccl.CommCount || !g_rccl.GetErrorString) {
         g_rccl = Rccl();
-        return fail(c, DRL_ERR_HIP, "RCCL lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather/ncclCommDestroy");
+        return fail(c, DRL_ERR_HIP, "RCCL lacks ncclGetUniqueId/ncclCommInitRank/ncclAllGather/ncclCommCount/ncclCommDestroy");
     }
     return DRL_OK;
 }
@@ -1946,8 +2064,18 @@ int drl_comm_init(drl_ctx* c, int rank, int nranks, const void* id_in) {
     HIP_TRY(c, hipSetDevice(c->device));
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
+    count_alloc();
     RCCL_TRY(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
     c->comm_rank = rank; c->comm_size = nranks;
+    return DRL_OK;
+}
+
+int drl_comm_size(drl_ctx* c, int* nranks_out) {
+    if (!c || !nranks_out) return DRL_ERR_ARG;
+    *nranks_out = 0;
+    if (!c->comm) return fail(c, DRL_ERR_STATE, "drl_comm_size: drl_comm_init was not called");
+    // what RCCL itself reports for the communicator it formed, not what the caller passed to drl_comm_init
+    RCCL_TRY(c, g_rccl.CommCount(c->comm, nranks_out));
     return DRL_OK;
 }
 

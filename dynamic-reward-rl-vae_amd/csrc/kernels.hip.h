@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256, (LDSW ? 1 : (MAXT <= 2 ? 3 : 1))) void vae_ker
                 if (d < a.dout[p]) {
                     float l = lv[r];
                     if (a.lv_clip > 0.0f) l = fminf(fmaxf(l, -a.lv_clip), a.lv_clip);
-                    cur[0][r] += __expf(0.5f * l) * a.eps[wout * a.dout[p] + d];
+                    // exp(l/2) as 2^(l * log2(e)/2): the one-instruction form every other exponential here takes
+                    cur[0][r] += __builtin_amdgcn_exp2f(0.72134752044448170f * l) * a.eps[wout * a.dout[p] + d];
                 }
             }
         }

@@ -18,9 +18,11 @@ SYMBOLS = [
     "drl_create", "drl_destroy", "drl_last_error", "drl_version", "drl_set_stream", "drl_synchronize",
     "drl_set_vae", "drl_set_lstm", "drl_set_lstm_math", "drl_score_batch", "drl_score_batch_dev", "drl_score_batch_dev_noalloc", "drl_score_series",
     "drl_vae_predict", "drl_q_predict", "drl_rollout_batch", "drl_set_rollout_mode", "drl_al_get_samples", "drl_profile_enable", "drl_profile_reset", "drl_profile_read",
-    "drl_last_lstm_variant", "drl_last_lstm_tile", "drl_last_call_overlapped",
-    "drl_comm_unique_id", "drl_comm_init", "drl_allgather_scores", "drl_comm_destroy",
+    "drl_last_lstm_variant", "drl_last_lstm_kernels", "drl_last_vae_variant", "drl_last_lstm_tile", "drl_last_call_overlapped",
+    "drl_comm_unique_id", "drl_comm_init", "drl_allgather_scores", "drl_comm_destroy", "drl_comm_size",
+    "drl_set_knob", "drl_debug_alloc_count",
 ]
+ABI_REVISION = 2          # DRL_ABI_REVISION of include/drlvae.h
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -40,7 +42,7 @@ class ScoreOpts(C.Structure):
         ("vae_center", C.c_void_p),
         ("vae_scale", C.c_void_p),
         ("vae_clip", C.c_float),
-        ("reserved", C.c_int32),
+        ("abi_revision", C.c_int32),
     ]
 
 
@@ -109,6 +111,10 @@ def load():
     lib.drl_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), _i64p]
     lib.drl_last_lstm_variant.argtypes = [vp]
     lib.drl_last_lstm_variant.restype = C.c_char_p
+    lib.drl_last_lstm_kernels.argtypes = [vp]
+    lib.drl_last_lstm_kernels.restype = C.c_char_p
+    lib.drl_last_vae_variant.argtypes = [vp]
+    lib.drl_last_vae_variant.restype = C.c_char_p
     lib.drl_last_lstm_tile.argtypes = [vp]
     lib.drl_last_lstm_tile.restype = C.c_int
     lib.drl_last_call_overlapped.argtypes = [vp]
@@ -116,5 +122,9 @@ def load():
     lib.drl_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     lib.drl_allgather_scores.argtypes = [vp, vp, vp, C.c_int64]
     lib.drl_comm_destroy.argtypes = [vp]
+    lib.drl_comm_size.argtypes = [vp, _i32p]
+    lib.drl_set_knob.argtypes = [vp, C.c_char_p, C.c_longlong]
+    lib.drl_debug_alloc_count.argtypes = []
+    lib.drl_debug_alloc_count.restype = C.c_longlong
     _lib = lib
     return lib

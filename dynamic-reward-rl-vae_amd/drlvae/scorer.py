@@ -67,6 +67,31 @@ class WindowScorer:
         m = {"fp32": 0, "f16x3": 1}.get(mode, mode)
         self._check(self._lib.drl_set_lstm_math(self._h, int(m)), "drl_set_lstm_math")
 
+    def set_knob(self, name: str, value: int):
+        """A test / measurement knob of the context (include/drlvae.h: drl_set_knob)."""
+        self._check(self._lib.drl_set_knob(self._h, name.encode(), int(value)), "drl_set_knob")
+
+    def knob(self, name: str, value: int, restore: int = 0):
+        """Context manager: the knob holds ``value`` inside the block and ``restore`` after it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.set_knob(name, value)
+            try:
+                yield self
+            finally:
+                self.set_knob(name, restore)
+        return cm()
+
+    @property
+    def version(self) -> str:
+        return self._lib.drl_version().decode()
+
+    def alloc_count(self) -> int:
+        """Resources the library has asked the HIP runtime for since it was loaded (process-wide)."""
+        return int(self._lib.drl_debug_alloc_count())
+
     def set_rollout_mode(self, mode):
         """"auto" (default), "fixed_point" or "sequential": which exact design ``rollout`` runs."""
         m = {"auto": 0, "fixed_point": 1, "sequential": 2}.get(mode, mode)
@@ -113,6 +138,7 @@ class WindowScorer:
               in_offset=None, vae_center=None, vae_scale=None, vae_clip=0.0, dev=False):
         o = _abi.ScoreOpts()
         o.struct_size = C.sizeof(_abi.ScoreOpts)
+        o.abi_revision = _abi.ABI_REVISION
         o.vae_lag = int(vae_lag)
         o.flag_mode = _MODES[flag_mode] if isinstance(flag_mode, str) else int(flag_mode)
         o.action_rule = _RULES[action_rule] if isinstance(action_rule, str) else int(action_rule)
@@ -307,12 +333,28 @@ class WindowScorer:
         self._check(self._lib.drl_allgather_scores(self._h, int(send.data_ptr()), int(recv.data_ptr()), nbytes),
                     "drl_allgather_scores")
 
+    def comm_size(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
+        n = C.c_int32(0)
+        self._check(self._lib.drl_comm_size(self._h, C.byref(n)), "drl_comm_size")
+        return int(n.value)
+
     def comm_destroy(self):
         self._check(self._lib.drl_comm_destroy(self._h), "drl_comm_destroy")
 
     @property
     def lstm_variant(self) -> str:
         return self._lib.drl_last_lstm_variant(self._h).decode()
+
+    @property
+    def lstm_kernels(self):
+        """The LSTM kernels the last fused scoring call launched, as rocprofv3 names them."""
+        k = self._lib.drl_last_lstm_kernels(self._h).decode()
+        return k.split(";") if k else []
+
+    @property
+    def vae_variant(self) -> str:
+        return self._lib.drl_last_vae_variant(self._h).decode()
 
     @property
     def lstm_tile(self) -> int:

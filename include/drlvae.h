@@ -61,6 +61,13 @@ typedef enum drl_action_rule {
                                needs DRL_FLAG_BOTH */
 } drl_action_rule;
 
+/* Revision of drl_score_opts' field MEANINGS (its size alone does not show every change): a caller sets
+ * opts.abi_revision = DRL_ABI_REVISION and a library built from another revision rejects the call with
+ * DRL_ERR_ARG instead of misreading the struct.
+ *   1  (libdrlvae 0.1, field then named `reserved`, left 0) vae_center / vae_scale were const float*
+ *   2  vae_center / vae_scale are const double* (sklearn's float64 RobustScaler parameters) */
+#define DRL_ABI_REVISION 2
+
 typedef struct drl_score_opts {
     int32_t struct_size;     /* sizeof(drl_score_opts), for forward compatibility */
     int32_t vae_lag;         /* 0 or 1, see "Window indexing" */
@@ -80,7 +87,7 @@ typedef struct drl_score_opts {
                                 float32, then / scale_ rounded to float32 (see robust_apply, kernels.hip.h) */
     const double* vae_scale; /* RobustScaler scale_ [W*F], finite and non-zero; required iff vae_center */
     float vae_clip;          /* clip of the scaled VAE input (myasp-wadi.py:139); <= 0 = none */
-    int32_t reserved;
+    int32_t abi_revision;    /* DRL_ABI_REVISION of the header the caller was compiled against */
 } drl_score_opts;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -92,7 +99,9 @@ void drl_destroy(drl_ctx* ctx);
 /* Message of the last failing call on ctx; with ctx == NULL the last drl_create failure of the
  * calling thread.  Never NULL. */
 const char* drl_last_error(drl_ctx* ctx);
-/* Library version string. */
+/* Library version string: "drlvae <version> (gfx950; abi <DRL_ABI_REVISION>; src <hash>)", where <hash> is the
+ * first 16 hex digits of the sha256 over the library's sources at build time (csrc/Makefile) — a prebuilt
+ * library that no longer matches the sources beside it is told apart by it (bench.py, tests/test_abi.py). */
 const char* drl_version(void);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own;
  * NULL restores the context's stream. */
@@ -153,13 +162,16 @@ int drl_score_batch(drl_ctx* ctx, const float* series, const int64_t* seg_offset
 int drl_score_batch_dev(drl_ctx* ctx, const float* series, const int64_t* seg_offsets, int n_seg,
                         int F, int W, const drl_score_opts* opts,
                         float* recon_err, float* q, int32_t* action, float* margin);
-/* drl_score_batch_dev for callers that cannot allocate — code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
- * same kernels and bit-identical results, but everything the call needs on the device beyond the
- * caller's buffers (per-series tables, option tables, the per-sample input projections of the
- * multivariate LSTM paths) lives in a file-scope array of 32 MiB that each GPU the library runs on
- * holds until the process ends; the call makes no hipMalloc / hipFree / hipHostMalloc and creates no
- * events (drl_profile_* does not see it).  Limits, rejected with DRL_ERR_ARG and a message:
+/* drl_score_batch_dev for callers that cannot allocate — tight serving loops, harnesses that forbid
+ * hipMalloc.  It has NO counterpart in the reference.  Same arguments, same kernels and bit-identical
+ * results, but everything the call needs on the device beyond the caller's buffers (per-series tables,
+ * option tables, the per-sample input projections of the multivariate LSTM paths) lives in a file-scope
+ * array of 32 MiB that each GPU the library runs on holds until the process ends; the call makes no
+ * hipMalloc / hipFree / hipHostMalloc, creates no events or streams and changes no function attribute
+ * (drl_profile_* does not see it; drl_debug_alloc_count does not move across it — tested).
+ * It is NOT capturable into a HIP graph: the tables are written on the host into one pinned block per
+ * context at call time and copied from there, and the next call waits for that copy on the host.
+ * Limits, rejected with DRL_ERR_ARG and a message:
  *   n_seg <= 1024;  W*F <= 8192;  total samples <= 32,512 when the LSTM is a projection path with
  *   hidden <= 64 (any F > 1, e.g. the WaDi / SMD QNet), <= 16,256 with hidden 65..128; the
  *   univariate H <= 128 network (in_dim 2, F = 1) keeps no projections and has no sample limit.
@@ -239,6 +251,9 @@ int drl_comm_unique_id(drl_ctx* ctx, void* id_out);
 int drl_comm_init(drl_ctx* ctx, int rank, int nranks, const void* id);
 int drl_allgather_scores(drl_ctx* ctx, const void* send_dev, void* recv_dev, int64_t bytes_per_rank);
 int drl_comm_destroy(drl_ctx* ctx);
+/* The number of ranks RCCL itself reports for the context's communicator (ncclCommCount) — evidence that
+ * the N-rank communicator was formed, as opposed to the nranks the caller asked drl_comm_init for. */
+int drl_comm_size(drl_ctx* ctx, int* nranks_out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 
@@ -253,6 +268,14 @@ int drl_profile_read(drl_ctx* ctx, int which, double* total_ms, int64_t* launche
  * "xproj+h128" (any input width, hidden 65..128), "gemv" (drl_q_predict on few states), "generic"
  * (fallback: projections unavailable), "rollout_seq" (drl_rollout_batch's sequential kernel). */
 const char* drl_last_lstm_variant(drl_ctx* ctx);
+/* The LSTM kernels the last fused scoring call launched, by the names rocprofv3 prints (without "void "),
+ * ';'-separated, e.g. "xproj_kernel<8>;lstm_rec2_kernel<8>;lstm_rec_kernel<8, true>": bench.py prices
+ * roofline.traffic from exactly these kernels' rows of the committed PMC summary. */
+const char* drl_last_lstm_kernels(drl_ctx* ctx);
+/* Name of the VAE kernel the last call used: "wide16" (wide windows staged through LDS, mean path), "chain"
+ * (narrow windows, explicit batches, and every call that passes eps), "chain/lds" (the same with its weights
+ * copied to LDS first: calls of at most one workgroup per CU). */
+const char* drl_last_vae_variant(drl_ctx* ctx);
 /* Windows per workgroup tile of that launch for the "h128i2" kernels (16, 32 or 64: chosen from the
  * size of the call; results are bit-identical across the three), 0 for the other variants. */
 int drl_last_lstm_tile(drl_ctx* ctx);
@@ -261,6 +284,27 @@ int drl_last_lstm_tile(drl_ctx* ctx);
  * 2 always).  Kernel durations read with drl_profile_read then overlap in time.  No counterpart in
  * the reference. */
 int drl_last_call_overlapped(drl_ctx* ctx);
+
+/* ---- test and measurement knobs (no counterpart in the reference) ----------------------------------- */
+
+/* Sets one of the context's knobs; the environment variables DRLVAE_<NAME IN CAPITALS> give their initial
+ * values and are read once, inside drl_create (no entry point calls getenv).  Names and values:
+ *   force_generic 0|1      explicit-state batches always take the fallback LSTM kernel
+ *   overlap 0|1|2          VAE kernel on the second stream: never | large and small calls (default) | always
+ *   rec2 0|1|2             two candidate states in one wave: never | whole rounds of tiles (default) | always
+ *   rollout 0|1|2          as drl_set_rollout_mode
+ *   gemv_rounds n          drl_q_predict batches of up to n states per CU take the matrix-vector kernel (-1: default)
+ *   vw16_pad / rec_lds_pad extra LDS bytes per workgroup of vae_wide16 / lstm_rec (occupancy experiments)
+ *   pbuf_max bytes         behave as if a larger projection buffer could not be allocated (-1: off)
+ *   pipe_min bytes, pipe_chunk samples, no_pipeline 0|1    the pipelined host path of drl_score_batch
+ *   no_fused_epilogue 0|1  action / margin always by finalize_kernel
+ *   rollout_dense 0|1      drl_rollout_batch: full passes only
+ * Unknown names: DRL_ERR_ARG. */
+int drl_set_knob(drl_ctx* ctx, const char* name, long long value);
+/* How many times the library has asked the HIP runtime (or RCCL) for a resource since it was loaded: device or
+ * pinned memory, an event, a stream, a communicator.  Process-wide.  Tests assert that it does not move across
+ * drl_score_batch_dev_noalloc. */
+long long drl_debug_alloc_count(void);
 
 #ifdef __cplusplus
 }

@@ -357,13 +357,14 @@ def precision_recall_f1(truth, pred):
 # ----------------------------------------------------------------------------- whole path
 
 
-def score_series_univariate(v, W, vae, lstm, flag_mode="quirk", actions=None, dtype=np.float32):
+def score_series_univariate(v, W, vae, lstm, flag_mode="quirk", actions=None, dtype=np.float32, eps=None):
     """Everything the path produces for one normalised univariate series: per window k
     (cursor k+W) the VAE mean-path reconstruction error of v[k..k+W-1], Q of the LSTM state
-    v[k+1..k+W] (+flags), greedy action, AL margin."""
+    v[k+1..k+W] (+flags), greedy action, AL margin.  ``eps`` [K, latent]: the reference's sampling
+    path with the noise given (myasp-A1.py:84, 140) instead of the mean path."""
     X = vae_windows_univariate(v, W)
     rec = vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"],
-                      vae["logvar_layer"], vae.get("logvar_clip", 10.0), dtype=dtype)
+                      vae["logvar_layer"], vae.get("logvar_clip", 10.0), eps=eps, dtype=dtype)
     err = recon_error(X, rec, dtype=dtype)
     if flag_mode == "quirk":
         S = states_list_univariate(v, W)
@@ -380,7 +381,7 @@ def score_series_univariate(v, W, vae, lstm, flag_mode="quirk", actions=None, dt
 
 
 def score_series_multivariate(x, W, vae, lstm, center=None, scale=None, clip=10.0,
-                              dtype=np.float32, chunk=4096):
+                              dtype=np.float32, chunk=4096, eps=None):
     """WaDi formulation (reference myasp-wadi.py:132-149, 248-254, 326-328) for cursors
     c = W .. N-1 (window k = c - W): err = penalty_array[c] (window of rows c-W+1..c, scaled and
     clipped), Q of both candidate states (raw values), action by the WaDi rule."""
@@ -394,7 +395,8 @@ def score_series_multivariate(x, W, vae, lstm, center=None, scale=None, clip=10.
         # penalty_array[c] for c = k+W is the window ending at c: all_windows row c-(W-1) = k+1
         X = vae_windows_multivariate(x, W, center, scale, clip, k0 + 1, k1 + 1)
         rec = vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"],
-                          vae["logvar_layer"], vae.get("logvar_clip", 10.0), dtype=dtype)
+                          vae["logvar_layer"], vae.get("logvar_clip", 10.0),
+                          eps=None if eps is None else eps[k0:k1], dtype=dtype)
         err[k0:k1] = recon_error(X, rec, dtype=dtype)
         S = states_multivariate(x, W, k0, k1)
         qq = lstm_q(S.reshape(-1, W, F + 1), lstm["kernel"], lstm["bias"], lstm["w_out"],

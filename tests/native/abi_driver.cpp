@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -89,7 +90,7 @@ int main() {
         std::vector<float> err(K), q(2 * K), margin(K);
         std::vector<int32_t> act(K);
         drl_score_opts o{};
-        o.struct_size = sizeof o; o.vae_lag = 1; o.flag_mode = DRL_FLAG_QUIRK; o.action_rule = DRL_ACTION_ARGMAX;
+        o.struct_size = sizeof o; o.abi_revision = DRL_ABI_REVISION; o.vae_lag = 1; o.flag_mode = DRL_FLAG_QUIRK; o.action_rule = DRL_ACTION_ARGMAX;
         for (int math = 0; math < 2; ++math) {
             CHECK(drl_set_lstm_math(ctx, math));
             CHECK(drl_score_batch(ctx, x.data(), off.data(), (int)lens.size(), 1, W, &o, err.data(), q.data(),
@@ -108,7 +109,7 @@ int main() {
         CHECK(drl_score_batch(ctx, x.data(), off.data(), (int)lens.size(), 1, W, &o, err.data(), q.data(), nullptr, nullptr));
         EXPECT(finite(err) && finite(q));
         // outputs optional
-        o = drl_score_opts{}; o.struct_size = sizeof o; o.vae_lag = 1;
+        o = drl_score_opts{}; o.struct_size = sizeof o; o.abi_revision = DRL_ABI_REVISION; o.vae_lag = 1;
         CHECK(drl_score_batch(ctx, x.data(), off.data(), (int)lens.size(), 1, W, &o, err.data(), nullptr, nullptr, nullptr));
         CHECK(drl_score_batch(ctx, x.data(), off.data(), (int)lens.size(), 1, W, &o, nullptr, q.data(), nullptr, nullptr));
         // one series through the single-series entry point
@@ -164,7 +165,7 @@ int main() {
         std::vector<float> err(K), q(4 * K), margin(K);
         std::vector<int32_t> act(K);
         drl_score_opts o{};
-        o.struct_size = sizeof o; o.vae_lag = 0; o.flag_mode = DRL_FLAG_BOTH; o.action_rule = DRL_ACTION_WADI;
+        o.struct_size = sizeof o; o.abi_revision = DRL_ABI_REVISION; o.vae_lag = 0; o.flag_mode = DRL_FLAG_BOTH; o.action_rule = DRL_ACTION_WADI;
         std::vector<double> cen64(cen.begin(), cen.end()), scl64(scl.begin(), scl.end());   // the ABI takes sklearn's float64
         o.vae_center = cen64.data(); o.vae_scale = scl64.data(); o.vae_clip = 10.0f;
         CHECK(drl_score_batch(ctx, x.data(), off.data(), (int)lens.size(), F, Wm, &o, err.data(), q.data(), act.data(), margin.data()));
@@ -181,6 +182,13 @@ int main() {
         const int64_t off1[2] = {0, 64};
         EXPECT(drl_score_batch(ctx, dummy, off1, 1, 1, 25, &o, dummy, nullptr, nullptr, nullptr) != 0);
         EXPECT(drl_score_batch(ctx, nullptr, off1, 1, 1, 25, &o, dummy, nullptr, nullptr, nullptr) != 0);
+        // a caller built against revision 1 of the struct (the field was `reserved`, 0) is refused, not misread
+        o = drl_score_opts{}; o.struct_size = sizeof o; o.vae_lag = 1;
+        EXPECT(drl_score_batch(ctx, dummy, off1, 1, 1, 25, &o, dummy, nullptr, nullptr, nullptr) == DRL_ERR_ARG);
+        EXPECT(std::strstr(drl_last_error(ctx), "abi_revision") != nullptr);
+        EXPECT(drl_set_knob(ctx, "no_such_knob", 1) == DRL_ERR_ARG);
+        EXPECT(drl_set_knob(ctx, "no_pipeline", 1) == DRL_OK && drl_set_knob(ctx, "no_pipeline", 0) == DRL_OK);
+        EXPECT(drl_debug_alloc_count() > 0);
         EXPECT(drl_set_lstm(ctx, 2, 130, 2, 1.0f, dummy, dummy, dummy, dummy) != 0);
         EXPECT(drl_create(9999, &ctx) != 0 || true);
     }

@@ -23,6 +23,20 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.drl_version()
 
 
+def test_library_is_built_from_the_sources_beside_it():
+    """drl_version carries the sha256 of the sources the library was compiled from (csrc/Makefile): a prebuilt
+    libdrlvae.so that no longer matches the tree fails here, before it can pass a GPU test unnoticed."""
+    import sys
+    from drlvae import _abi
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_hash import src_hash
+    v = _abi.load().drl_version().decode()
+    m = re.search(r"src ([0-9a-f]{16})\)", v)
+    assert m, v
+    assert m.group(1) == src_hash(), f"{v}: stale library, rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+    assert f"abi {_abi.ABI_REVISION};" in v
+
+
 def test_opts_struct_layout_matches_header():
     from drlvae import _abi
     body = re.search(r"typedef struct drl_score_opts \{(.*?)\} drl_score_opts;", _header(), re.S).group(1)

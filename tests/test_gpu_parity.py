@@ -332,6 +332,76 @@ def test_q_predict_and_vae_predict(scorer, a1, ckpt_a1):
     np.testing.assert_allclose(rec, want, rtol=RTOL, atol=1e-7)
 
 
+# ----------------------------------------------------------------------------------- the sampling path
+def test_eps_on_the_fused_entry_points_narrow_vae(scorer, a1, ckpt_a1):
+    """The reference's vae.predict always draws eps (myasp-A1.py:78-84, 94, 140); with the draws handed in, the
+    fused call must give the reference's reward: host path (drl_score_batch) and device path
+    (drl_score_batch_dev), the LSTM outputs of the same call untouched, a ragged batch included."""
+    import torch
+    lstm, vae = ckpt_a1
+    scorer.set_vae(vae)
+    scorer.set_lstm(lstm)
+    rng = np.random.default_rng(77)
+    vs = [a1["series"][i] for i in (0, 3, 5)]
+    off = np.concatenate([[0], np.cumsum([len(v) for v in vs])]).astype(np.int64)
+    K = int(sum(len(v) - W for v in vs))
+    eps = rng.normal(size=(K, 10)).astype(np.float32)
+    out = scorer.score(np.concatenate(vs), W, off, flag_mode="quirk", eps=eps)
+    assert scorer.vae_variant.startswith("chain")
+    mean = scorer.score(np.concatenate(vs), W, off, flag_mode="quirk")
+    assert np.array_equal(out["q"].view(np.uint32), mean["q"].view(np.uint32))          # eps touches the reward only
+    assert not np.array_equal(out["err"], mean["err"])
+    pos = 0
+    for v in vs:
+        k = len(v) - W
+        want = orc.score_series_univariate(v, W, vae, lstm, "quirk", dtype=np.float64, eps=eps[pos:pos + k])
+        np.testing.assert_allclose(out["err"][pos:pos + k], want["err"], rtol=RTOL)
+        assert_q_close(out["q"][pos:pos + k], want["q"])
+        pos += k
+    dev = torch.device("cuda", scorer.device)
+    o = {"err": torch.empty(K, dtype=torch.float32, device=dev), "q": torch.empty((K, 1, 2), dtype=torch.float32, device=dev)}
+    scorer.score_dev(torch.from_numpy(np.concatenate(vs)).to(dev), W, off, o, vae_lag=1, flag_mode="quirk",
+                     eps=torch.from_numpy(eps).to(dev))
+    scorer.synchronize()
+    assert np.array_equal(o["err"].cpu().numpy().view(np.uint32), out["err"].view(np.uint32))
+
+
+@pytest.mark.parametrize("F,hidden", [(38, 128), (123, 128), (38, 100)])
+def test_eps_with_wide_windows_and_logvar_on_the_clip(scorer, F, hidden):
+    """Wide windows (SMD D = 950, WaDi D = 3075: myasp-wadi.py:101-117, 145) with eps leave vae_wide16_kernel for
+    the chain kernel's wide instantiation (the only one with the logvar head).  The logvar biases are set so that
+    the latent dimensions sit far below the -10 clip, just inside it, just outside it, and far above +10
+    (exp(5) = 148 times eps): the clip and the exponential are held to the same 1e-5 as everything else."""
+    rng = np.random.default_rng(900 + F + hidden)
+    N = 25 + 150
+    D = W * F
+    x = rng.random((N, F), dtype=np.float32)
+    vae = synth_vae(rng, [D, hidden, 10, hidden, D], 1)
+    vae["kernels"][2] *= 0.02                           # logvar = its bias +- a few hundredths
+    vae["biases"][2] = np.array([-40, -10.5, -10.0, -9.5, 0, 0.3, 9.5, 10.0, 10.5, 40], np.float32)
+    sample = rng.choice(np.arange(W, N), size=60, replace=False)
+    center, scale = orc.robust_scaler_fit(np.array([x[i - W + 1:i + 1].reshape(-1) for i in sample]))
+    K = N - W
+    eps = rng.normal(size=(K, 10)).astype(np.float32)
+    scorer.set_vae(vae)
+    kw = dict(vae_lag=0, want=("err",), vae_center=center, vae_scale=scale, vae_clip=10.0)
+    got = scorer.score(x, W, eps=eps, **kw)["err"]
+    assert scorer.vae_variant.startswith("chain")
+    mean = scorer.score(x, W, **kw)["err"]
+    assert scorer.vae_variant == ("wide16" if hidden > 96 else "chain")
+    X = orc.vae_windows_multivariate(x, W, center, scale, 10.0, 1, K + 1)
+    lv = np.maximum(X.astype(np.float64) @ vae["kernels"][0] + vae["biases"][0], 0) @ vae["kernels"][2].astype(np.float64) + vae["biases"][2]
+    assert (lv[:, 0] < -10).all() and (lv[:, 9] > 10).all()
+    for j, edge in ((2, -10.0), (7, 10.0)):             # windows on both sides of each clip edge
+        assert (lv[:, j] < edge).any() and (lv[:, j] > edge).any() and np.abs(lv[:, j] - edge).max() < 0.5
+    for e, ee in ((eps, got), (None, mean)):
+        rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], 1, 2, 10.0, eps=e, dtype=np.float64)
+        np.testing.assert_allclose(ee, orc.recon_error(X, rec, np.float64), rtol=RTOL)
+    # and the explicit-batch entry point with the same draws
+    _, e2 = scorer.vae_predict(X, eps=eps, return_err=True)
+    np.testing.assert_allclose(e2, got, rtol=2e-6)
+
+
 # ----------------------------------------------------------------------------------- multivariate
 @pytest.mark.parametrize("F,H,N", [(3, 64, 300), (38, 64, 700), (38, 128, 260), (123, 64, 400)])
 def test_multivariate_wadi_formulation(scorer, F, H, N):
@@ -433,11 +503,8 @@ def test_projection_buffer_unavailable_falls_back(scorer):
         kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", want=("q", "action"))
         ref = scorer.score(x, W, **kw)
         assert scorer.lstm_variant.startswith("xproj")
-        os.environ["DRLVAE_PBUF_MAX"] = "1024"
-        try:
+        with scorer.knob("pbuf_max", 1024, restore=-1):
             got = scorer.score(x, W, **kw)
-        finally:
-            del os.environ["DRLVAE_PBUF_MAX"]
         assert scorer.lstm_variant == "generic"
         S = orc.states_multivariate(x, W, 0, N - W)
         want = orc.lstm_q(S.reshape(-1, W, F + 1), lstm["kernel"], lstm["bias"], lstm["w_out"], lstm["b_out"], 1.0,
@@ -704,23 +771,20 @@ def test_rollout_reproduces_reference_performance_files(scorer, a1, ckpt_a1, ckp
         assert np.array_equal(got_a[:80], orc.rollout_greedy(v[:130], 50, l64["kernel"], l64["bias"], l64["w_out"], l64["b_out"]))
         # all 67 A1 series, 1,920 alarms, 33 passes.  From the second pass on the fixed point scores only the
         # 16-window tiles that a changed flag reaches: same passes, same actions, same Q bits as with full passes
-        # (DRLVAE_ROLLOUT_DENSE=1) and as the sequential kernel
+        # (knob rollout_dense) and as the sequential kernel
         scorer.set_lstm(lstm)
         flat = np.concatenate(a1["series"])
         offs = np.concatenate([[0], np.cumsum([len(v) for v in a1["series"]])])
         scorer.set_rollout_mode("fixed_point")
         sparse_a, sparse_q = scorer.rollout(flat, W, offs, return_q=True)
         sparse_passes = scorer.last_rollout_passes
-        os.environ["DRLVAE_ROLLOUT_DENSE"] = "1"
-        try:
+        with scorer.knob("rollout_dense", 1):
             dense_a, dense_q = scorer.rollout(flat, W, offs, return_q=True)
             assert scorer.last_rollout_passes == sparse_passes == 33
             # auto with full passes only (33 of 2.4 ms against 28 ms of stepping): hands over after its budget
             scorer.set_rollout_mode("auto")
             auto = scorer.rollout(flat, W, offs)
             assert scorer.lstm_variant == "rollout_seq" and 0 < scorer.last_rollout_passes < 33
-        finally:
-            del os.environ["DRLVAE_ROLLOUT_DENSE"]
         assert np.array_equal(sparse_a, dense_a) and np.array_equal(sparse_q.view(np.uint32), dense_q.view(np.uint32))
         assert np.array_equal(auto, dense_a) and int(auto.sum()) == 1920
         scorer.set_rollout_mode("sequential")
@@ -896,16 +960,10 @@ def test_pipelined_host_call_equals_the_one_shot_call(scorer):
     rng = np.random.default_rng(2025)
 
     def both(x, Wn, off, **kw):
-        os.environ["DRLVAE_NO_PIPELINE"] = "1"
-        try:
+        with scorer.knob("no_pipeline", 1):
             ref = scorer.score(x, Wn, off, **kw)
-        finally:
-            del os.environ["DRLVAE_NO_PIPELINE"]
-        os.environ["DRLVAE_PIPE_CHUNK"] = "17000"          # samples per chunk: several chunks at these test sizes
-        try:
+        with scorer.knob("pipe_chunk", 17000):             # samples per chunk: several chunks at these test sizes
             got = scorer.score(x, Wn, off, **kw)
-        finally:
-            del os.environ["DRLVAE_PIPE_CHUNK"]
         for k in ref:
             assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), k
         return got

@@ -94,6 +94,11 @@ def test_univariate_random_shapes(scorer, seed):
     kw = dict(flag_mode=mode)
     if mode == "explicit":
         kw["flags"] = np.concatenate(flags)
+    K = int(sum(max(0, n - Wn) for n in lens))
+    latent = vae["kernels"][vae["mu_layer"]].shape[1]
+    eps = rng.normal(size=(K, latent)).astype(np.float32) if seed % 4 == 1 else None     # the reference's sampling path
+    if eps is not None:
+        kw["eps"] = eps
     if device_minmax:
         kw["in_scale"] = np.array([p[0] for p in params], np.float32)
         kw["in_offset"] = np.array([p[1] for p in params], np.float32)
@@ -110,11 +115,12 @@ def test_univariate_random_shapes(scorer, seed):
         if k == 0:
             continue
         X = orc.vae_windows_univariate(v, Wn)
+        e_ = None if eps is None else eps[pos:pos + k]
         rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"],
-                              10.0, dtype=np.float64)
+                              10.0, eps=e_, dtype=np.float64)
         err = orc.recon_error(X, rec, dtype=np.float64)
         err32 = orc.recon_error(X, orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"],
-                                                   vae["logvar_layer"], 10.0, dtype=np.float32), dtype=np.float32)
+                                                   vae["logvar_layer"], 10.0, eps=e_, dtype=np.float32), dtype=np.float32)
         S = orc.states_list_univariate(v, Wn)
         if mode == "zeros":
             S[:, :, 1] = 0
@@ -161,9 +167,13 @@ def test_multivariate_random_shapes(scorer, seed):
         of_ = rng.uniform(-0.5, 0.5, n_seg).astype(np.float32)
         extra = dict(in_scale=sc_, in_offset=of_)
         xs = [(x * s_ + o_).astype(np.float32) for x, s_, o_ in zip(raw, sc_, of_)]   # two fp32 roundings
+    K = int(sum(max(0, n - Wn) for n in lens))
+    latent = vae["kernels"][vae["mu_layer"]].shape[1]
+    eps = rng.normal(size=(K, latent)).astype(np.float32) if seed % 4 == 2 else None     # the reference's sampling path
+    if eps is not None:
+        extra["eps"] = eps
     out = scorer.score(np.concatenate(raw), Wn, off, vae_lag=0, flag_mode="both", action_rule="wadi",
                        vae_center=center, vae_scale=scale, vae_clip=clip, **extra)
-    K = int(sum(max(0, n - Wn) for n in lens))
     assert out["q"].shape == (K, 2, 2)
     assert scorer.lstm_variant == ("xproj+h128" if H > 64 else "xproj+rec")
     pos = 0
@@ -171,8 +181,9 @@ def test_multivariate_random_shapes(scorer, seed):
         k = max(0, n - Wn)
         if k == 0:
             continue
-        want = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float64)
-        want32 = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float32)
+        e_ = None if eps is None else eps[pos:pos + k]
+        want = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float64, eps=e_)
+        want32 = orc.score_series_multivariate(x, Wn, vae, lstm, center, scale, clip if scaled else 10.0, dtype=np.float32, eps=e_)
         np.testing.assert_allclose(out["err"][pos:pos + k], want["err"], rtol=RTOL, atol=_err_atol(want32["err"], want["err"]),
                                    err_msg=f"W={Wn} F={F} hid={hid} dec={dec} {scorer._lib.drl_last_lstm_variant(scorer._h)}")
         assert _q_ok(out["q"][pos:pos + k], want["q"], lstm), (Wn, F, H, scorer.lstm_variant, _nrel(out["q"][pos:pos + k], want["q"]))
@@ -412,12 +423,9 @@ def test_rollout_designs_agree_on_random_networks(scorer, seed):
         scorer.set_rollout_mode("fixed_point")
         a_sp, q_sp = scorer.rollout(v, Wn, off, return_q=True)
         passes = scorer.last_rollout_passes
-        os.environ["DRLVAE_ROLLOUT_DENSE"] = "1"
-        try:
+        with scorer.knob("rollout_dense", 1):
             a_de, q_de = scorer.rollout(v, Wn, off, return_q=True)
             assert scorer.last_rollout_passes == passes
-        finally:
-            del os.environ["DRLVAE_ROLLOUT_DENSE"]
         scorer.set_rollout_mode("sequential")
         a_sq, q_sq = scorer.rollout(v, Wn, off, return_q=True)
         scorer.set_rollout_mode("auto")
@@ -458,17 +466,10 @@ def test_pipelined_host_path_random_chunk_plans(scorer, seed):
         kw["in_offset"] = rng.uniform(-0.2, 0.2, n_seg).astype(np.float32)
     scorer.set_vae(vae)
     scorer.set_lstm(lstm)
-    os.environ["DRLVAE_NO_PIPELINE"] = "1"
-    try:
+    with scorer.knob("no_pipeline", 1):
         ref = scorer.score(x, Wn, off, **kw)
-    finally:
-        del os.environ["DRLVAE_NO_PIPELINE"]
-    os.environ["DRLVAE_PIPE_MIN"] = "1"
-    os.environ["DRLVAE_PIPE_CHUNK"] = str(int(rng.choice([4 * Wn, 777, 5000, 20000, 100000])))
-    try:
+    with scorer.knob("pipe_min", 1), scorer.knob("pipe_chunk", int(rng.choice([4 * Wn, 777, 5000, 20000, 100000]))):
         got = scorer.score(x, Wn, off, **kw)
-    finally:
-        del os.environ["DRLVAE_PIPE_MIN"], os.environ["DRLVAE_PIPE_CHUNK"]
     K = int(sum(max(0, n - Wn) for n in lens))
     assert got["err"].shape == (K,)
     for k in ref:
@@ -584,11 +585,8 @@ def test_argmax_epilogue_in_the_lstm_kernels_equals_finalize_kernel(scorer, seed
     sc.set_lstm(lstm)
     xs = x if F > 1 else x[:, 0]
     got = sc.score(xs, Wn, off, want=("q", "action", "margin"), **kw)
-    os.environ["DRLVAE_NO_FUSED_EPILOGUE"] = "1"
-    try:
+    with sc.knob("no_fused_epilogue", 1):
         ref = sc.score(xs, Wn, off, want=("q", "action", "margin"), **kw)
-    finally:
-        del os.environ["DRLVAE_NO_FUSED_EPILOGUE"]
     for k in ("q", "action", "margin"):
         assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), (k, F, H, A, Wn, kw, sc.lstm_variant)
     q = got["q"]

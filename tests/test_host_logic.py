@@ -189,6 +189,70 @@ def test_sharded_scoring_equals_single_process_gloo_world2(ckpt_a1):
             np.testing.assert_array_equal(got["action"], want["action"])
 
 
+def _mv_case():
+    """A small WaDi-formulation problem (two candidate states per window: S = 2 pack layout)."""
+    from test_gpu_parity import synth_lstm, synth_vae
+    rng = np.random.default_rng(88)
+    F, Wm = 3, 5
+    vae = synth_vae(rng, [Wm * F, 16, 4, 16, Wm * F], 1)
+    lstm = synth_lstm(rng, F + 1, 8)
+    center, scale = rng.uniform(0.3, 0.7, Wm * F), rng.uniform(0.2, 0.6, Wm * F)
+    x = rng.random((Wm + 61, F), dtype=np.float32)
+    return F, Wm, vae, lstm, center, scale, x
+
+
+def _worker_mv(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-reward-rl-vae_amd"), os.path.join(ROOT, "tests")]
+    import torch
+    import torch.distributed as dist
+    from drlvae.dist import score_stream_sharded
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    F, Wm, vae, lstm, center, scale, x = _mv_case()
+
+    def score_fn(xs, W, vae_lag=0, flag_mode="both", **kw):
+        assert flag_mode == "both" and vae_lag == 0
+        return orc.score_series_multivariate(xs, W, vae, lstm, center, scale, 10.0)
+
+    out = {n: score_stream_sharded(score_fn, x[:n], Wm, vae_lag=0, flag_mode="both") for n in (Wm + 61, Wm + 7)}
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+def test_sharded_two_candidate_stream_gloo_world8_uneven_and_empty_shards():
+    """world 8 (the node the north star names), a multivariate stream scored with both candidate states: the
+    S = 2 layout of the packed all-gather, shards of 7 and 8 windows (61 over 8 ranks), and a stream of 7 windows
+    that leaves rank 0 without any.  Every rank must end up with the single-process result."""
+    import torch.multiprocessing as mp
+    from drlvae.dist import shard_stream
+    world = 8
+    F, Wm, vae, lstm, center, scale, x = _mv_case()
+    sizes = [shard_stream(Wm + 61, Wm, r, world, 0)[3] - shard_stream(Wm + 61, Wm, r, world, 0)[2] for r in range(world)]
+    assert sorted(set(sizes)) == [7, 8] and sum(sizes) == 61
+    small = [shard_stream(Wm + 7, Wm, r, world, 0)[3] - shard_stream(Wm + 7, Wm, r, world, 0)[2] for r in range(world)]
+    assert small.count(0) == 1 and sum(small) == 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mv, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for n in (Wm + 61, Wm + 7):
+        want = orc.score_series_multivariate(x[:n], Wm, vae, lstm, center, scale, 10.0)
+        for rank in range(world):
+            got = results[rank][n]
+            assert got["q"].shape == (n - Wm, 2, 2) and got["action"].dtype == np.int32
+            for k in ("err", "q", "margin"):
+                np.testing.assert_allclose(got[k], want[k], rtol=2e-6, atol=1e-6, err_msg=f"{n}/{k}/rank{rank}")
+            np.testing.assert_array_equal(got["action"], want["action"])
+
+
 def test_dynamic_coef_update_matches_reference_formula():
     """reference myasp-A1.py:235-238 / :455 (target 0, alpha 0.001, clip to [0.1, 10])."""
     from drlvae.compat import update_dynamic_coef_proportional as upd

@@ -1,7 +1,8 @@
 """The entry point that allocates nothing (drl_score_batch_dev_noalloc, include/drlvae.h): called through
 the C-ABI and checked against drl_score_batch_dev — same kernels, so bit for bit — on two calls in a row,
 the second with a smaller input; both the projection paths (whose per-sample projections live in the
-library's file-scope scratch array) and the univariate path; and its size limits."""
+library's file-scope scratch array) and the univariate path; its size limits; and that it really allocates
+nothing (the library's own count of its allocation sites, and hipMemGetInfo, across calls with new layouts)."""
 import numpy as np
 import pytest
 
@@ -160,3 +161,56 @@ def test_noalloc_calls_back_to_back_without_synchronising(seed):
                 assert float(outs[1]["err"].min()) >= 0
     finally:
         sc.close()
+
+
+@pytest.mark.parametrize("F,H", [(38, 64), (12, 128), (1, 128)])
+def test_noalloc_entry_point_allocates_nothing(F, H):
+    """drl_debug_alloc_count (bumped at every hipMalloc / hipHostMalloc / event / stream / communicator site of
+    the library) and the free device memory (hipMemGetInfo) do not move across calls of the no-allocation entry
+    point — calls with layouts, scaler tables and sizes the context has never seen, which make the allocating
+    entry point grow its tables and projections (shown on a second context: the counter does count)."""
+    import torch
+    from drlvae.scorer import WindowScorer
+    rng = np.random.default_rng(77 * F + H)
+    vae, lstm = _nets(rng, F, H)
+    dev = torch.device("cuda", 0)
+    D = W * F
+    if F > 1:
+        kw = dict(vae_lag=0, flag_mode="both", action_rule="wadi", vae_center=rng.uniform(0.3, 0.7, D),
+                  vae_scale=rng.uniform(0.2, 0.6, D), vae_clip=10.0)
+    else:
+        kw = dict(vae_lag=1, flag_mode="quirk", action_rule="argmax")
+    plans = [[900, 40, 300], [5000], [W + 1, 7, 2200, 1300], [12_000]]
+    data = []
+    for lens in plans:                                    # every tensor exists before the counters are read
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        K = int(np.maximum(np.diff(off) - W, 0).sum())
+        S = 2 if F > 1 else 1
+        x = torch.from_numpy(rng.random((int(off[-1]), F), dtype=np.float32)).to(dev)
+        out = {"err": torch.empty(K, dtype=torch.float32, device=dev), "q": torch.empty((K, S, 2), dtype=torch.float32, device=dev),
+               "action": torch.empty(K, dtype=torch.int32, device=dev), "margin": torch.empty(K, dtype=torch.float32, device=dev)}
+        data.append((x if F > 1 else x.reshape(-1), off, out))
+    sc = WindowScorer(0)
+    other = WindowScorer(0)
+    try:
+        for s_ in (sc, other):
+            s_.set_vae(vae)
+            s_.set_lstm(lstm)
+        # once through the no-allocation path: the runtime loads each kernel's code on its first launch
+        sc.score_dev(data[0][0], W, data[0][1], data[0][2], noalloc=True, **kw)
+        sc.synchronize()
+        torch.cuda.synchronize()
+        count0, free0 = sc.alloc_count(), torch.cuda.mem_get_info(0)[0]
+        for x, off, out in data[1:] + data[:1]:
+            sc.score_dev(x, W, off, out, noalloc=True, **kw)
+        sc.synchronize()
+        torch.cuda.synchronize()
+        assert sc.alloc_count() == count0, "drl_score_batch_dev_noalloc reached an allocation site"
+        assert torch.cuda.mem_get_info(0)[0] == free0
+        # the counter is live: the allocating entry point on a fresh context does move it
+        other.score_dev(data[3][0], W, data[3][1], data[3][2], **kw)
+        other.synchronize()
+        assert other.alloc_count() > count0
+    finally:
+        sc.close()
+        other.close()

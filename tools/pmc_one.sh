@@ -5,7 +5,7 @@ set -e
 w=$1; shift
 out=gpurun_out/pmc1; rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-args="--workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-alt $*"
+args="--workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-alt --no-others $*"
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $out/sq -- python bench.py $args > $out/sq.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $out/inst -- python bench.py $args > $out/inst.log 2>&1
 python - <<'PY'

@@ -13,11 +13,11 @@ done
 # the n_hidden_dim = 128 variants of the multivariate configurations (C3 "H128")
 timeout -k 10 300 python -u bench.py --workload c3 --hidden 128 --steps 40 --warmup 5 --no-cpu-baseline > $out/bench_c3_h128.json 2> $out/bench_c3_h128.err
 timeout -k 10 300 python -u bench.py --workload c4 --hidden 128 --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_c4_h128.json 2> $out/bench_c4_h128.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --no-cpu-baseline --no-alt > $out/trace_c2.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2 -- python bench.py --no-cpu-baseline --no-alt --no-others > $out/trace_c2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c4 -- python bench.py --workload c4 --steps 5 --warmup 2 --no-cpu-baseline > $out/trace_c4.log 2>&1
 # PMC passes, one counter group per run (a run may hold at most 8 SQ / 4 TCC counters): C2 and C4
 for w in c2 c4; do
-  args="--workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-alt"
+  args="--workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-alt --no-others"
   timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $out/pmc_${w}_sq -- python bench.py $args > $out/pmc_${w}_sq.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_${w}_fetch -- python bench.py $args > $out/pmc_${w}_fetch.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_${w}_write -- python bench.py $args > $out/pmc_${w}_write.log 2>&1

@@ -16,15 +16,14 @@ def timed(values, offsets, label):
     res = {}
     for mode in ("fixed_point_full_passes", "fixed_point", "sequential", "auto"):
         sc.set_rollout_mode("fixed_point" if mode.startswith("fixed") else mode)
-        if mode == "fixed_point_full_passes":
-            os.environ["DRLVAE_ROLLOUT_DENSE"] = "1"
+        sc.set_knob("rollout_dense", 1 if mode == "fixed_point_full_passes" else 0)
         for _ in range(2):
             sc.rollout(values, W, offsets)
         t0 = time.perf_counter()
         for _ in range(5):
             a = sc.rollout(values, W, offsets)
         res[mode] = ((time.perf_counter() - t0) / 5, a, sc.last_rollout_passes)
-        os.environ.pop("DRLVAE_ROLLOUT_DENSE", None)
+        sc.set_knob("rollout_dense", 0)
     (tf, af, pf), (ts, as_, _), (ta, aa, pa) = res["fixed_point"], res["sequential"], res["auto"]
     td, ad, pd_ = res["fixed_point_full_passes"]
     assert np.array_equal(af, as_) and np.array_equal(af, aa) and np.array_equal(af, ad) and pd_ == pf
