@@ -5,6 +5,7 @@
 #include "lstm_f16x3.hip.h"
 #include "lstm_w16.hip.h"
 #include "vae_wide16.hip.h"
+#include "vae_wide16pp.hip.h"
 
 #include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
@@ -126,6 +127,9 @@ struct drl_ctx {
     bool no_pipeline = false;     // host path: always the one-shot copy
     bool no_fused_epilogue = false;   // action / margin always by finalize_kernel
     bool rollout_dense = false;   // drl_rollout_batch: full passes only
+    int vae_pp = 0;               // wide windows: the ping-pong kernel (two tiles per workgroup, persistent): 0 never (default:
+                                  // measured slower than vae_wide16_kernel), 1 calls of more 64-window
+                                  // tiles than CUs, 2 whenever its LDS fits
     bool last_overlap = false;
     std::string err;
     VaeHost vae;
@@ -555,6 +559,8 @@ int drl_create(int device_id, drl_ctx** out) {
             attr(reinterpret_cast<const void*>(vae_kernel<DRL_VAE_MAX_TILES, true>), CHAIN_LDS_MAX) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<false>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<false>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, false>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(lstm_rec2_kernel<8>), 160 * 1024) &&
@@ -569,7 +575,7 @@ int drl_create(int device_id, drl_ctx** out) {
     }
     // the environment is read here and nowhere else
     for (const char* name : {"force_generic", "overlap", "rec2", "rollout", "gemv_rounds", "vw16_pad", "rec_lds_pad", "pbuf_max",
-                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense"}) {
+                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense", "vae_pp"}) {
         std::string var = "DRLVAE_";
         for (const char* p = name; *p; ++p) var += (char)toupper((unsigned char)*p);
         if (const char* e = getenv(var.c_str())) (void)drl_set_knob(c, name, atoll(e));
@@ -649,9 +655,16 @@ int drl_set_knob(drl_ctx* c, const char* name, long long v) {
     else if (n == "no_pipeline") c->no_pipeline = v != 0;
     else if (n == "no_fused_epilogue") c->no_fused_epilogue = v != 0;
     else if (n == "rollout_dense") c->rollout_dense = v != 0;
+    else if (n == "vae_pp") c->vae_pp = (int)std::min<long long>(2, std::max<long long>(0, v));
     else return fail(c, DRL_ERR_ARG, "drl_set_knob: unknown knob '%s'", name);
     return DRL_OK;
 }
+
+#ifdef VWP_STAMPS
+int drl_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vwp_dbg), std::min<size_t>((size_t)n, 2 * 64 * 3) * sizeof(unsigned long long));
+}
+#endif
 
 long long drl_debug_alloc_count(void) { return g_alloc_count.load(std::memory_order_relaxed); }
 
@@ -1121,6 +1134,10 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
     seg.samp_off = sh.d_samp; seg.win_off = sh.d_win; seg.tile_off = sh.d_t32;
     seg.in_scale = od.in_scale; seg.in_offset = od.in_offset; seg.n_seg = n_seg; seg.W = W;
 
+    // Wide windows, more 64-window tiles than CUs: the ping-pong VAE kernel (vae_wide16pp.hip.h).  Its persistent
+    // workgroups want every CU for the whole launch, so such a call keeps its VAE kernel on the main stream.
+    const bool pp_wanted = want_vae && c->vae.wide16 && !d_eps && c->vae_pp != 0 && (((uintptr_t)d_series) & 15) == 0 &&
+                           (c->vae_pp == 2 || sh.tiles64 > c->n_cu);
     auto launch_vae = [&](hipStream_t vst) -> int {
         VaeArgs a;
         memset(&a, 0, sizeof a);
@@ -1133,12 +1150,20 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         size_t wide_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
         if (c->vw16_pad) wide_lds = std::min<size_t>(wide_lds + (size_t)c->vw16_pad, 160 * 1024);   // measurement knob: fewer workgroups per CU
         const bool wide = c->vae.wide16 && !d_eps && wide_lds <= 160 * 1024;
+        // the ping-pong form: two regions (+ up to 3 floats each for the 16-byte alignment of their loads) and one ring
+        const int xr_pp = xr_floats + 4;
+        const size_t pp_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)2 * xr_pp) * sizeof(float);
+        const bool use_pp = wide && pp_wanted && pp_lds <= 160 * 1024;
         if (prof) prof_begin(c, 1, vst);
         if (wide) {
             if (wide_lds > c->wide_lds_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16pp_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 c->wide_lds_set = 160 * 1024;
             }
@@ -1154,12 +1179,20 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 const size_t span = lastp > 1 ? c->vae.w16_off[lastp] - c->vae.w16_off[1] : 0;
                 b16.mid_floats = (span > 0 && span <= 2 * VW16_SLAB && span % 4 == 0) ? (int)span : 0;
             }
-            a.seg.tile_off = sh.d_t64;               // a workgroup = one 64-window tile
+            a.seg.tile_off = sh.d_t64;               // a tile = 64 windows of one series
             a.n_tiles = sh.tiles64;
-            const dim3 grid(sh.tiles64);
-            if (a.rs) hipLaunchKernelGGL(vae_wide16_kernel<true>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);
-            else hipLaunchKernelGGL(vae_wide16_kernel<false>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);
-            c->last_vae_variant = "wide16";
+            if (use_pp) {
+                // two tiles per workgroup in ping-pong, persistent: every CU a balanced share of the tiles
+                const dim3 grid(std::min(c->n_cu, (sh.tiles64 + 1) / 2));
+                if (a.rs) hipLaunchKernelGGL(vae_wide16pp_kernel<true>, grid, dim3(VWP_THREADS), pp_lds, vst, a, b16, xr_pp);
+                else hipLaunchKernelGGL(vae_wide16pp_kernel<false>, grid, dim3(VWP_THREADS), pp_lds, vst, a, b16, xr_pp);
+                c->last_vae_variant = "wide16pp";
+            } else {
+                const dim3 grid(sh.tiles64);         // a workgroup = one tile
+                if (a.rs) hipLaunchKernelGGL(vae_wide16_kernel<true>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);
+                else hipLaunchKernelGGL(vae_wide16_kernel<false>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);
+                c->last_vae_variant = "wide16";
+            }
         } else {
             int rcl = launch_vae_chain(c, a, sh.tiles32, vst);
             if (rcl) return rcl;
@@ -1177,7 +1210,7 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
     const bool big_wide = sh.K_total >= 65536;
     const bool small = (long long)sh.tiles32 * (o->flag_mode == DRL_FLAG_BOTH ? 2 : 1) <= (long long)c->n_cu * 3 / 4;
     const bool overlap = want_vae && want_q && c->aux_stream &&
-                         (c->overlap_mode == 2 || (c->overlap_mode == 1 && (big_wide || small)));
+                         (c->overlap_mode == 2 || (c->overlap_mode == 1 && ((big_wide && !pp_wanted) || small)));
     c->last_overlap = overlap;
     if (want_vae && !overlap && (rc = launch_vae(c->stream))) return rc;
     if (overlap) {

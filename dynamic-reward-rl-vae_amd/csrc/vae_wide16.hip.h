@@ -151,6 +151,12 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
             ? a.rs + (size_t)(threadIdx.x >> 5) * a.rsP + 4 * (threadIdx.x & 7) + ((threadIdx.x & 31) >> 3) : w;
         vw16_stage_store(stg, wt);
         if (SCALED && threadIdx.x < 128) side[threadIdx.x] = ss[0];
+        // The biases above came from global memory.  Unless they are consumed HERE, the compiler's wait-count pass
+        // keeps "cur[T] may still be in flight" alive around the loop's back edge and puts s_waitcnt vmcnt(7..0) in
+        // front of the first eight MFMAs of EVERY slab — which then also wait for the loads of the next slab issued
+        // a few instructions earlier (a full L2 round trip exposed per slab instead of hidden under 64 MFMAs).
+#pragma unroll
+        for (int T = 0; T < 8; ++T) asm volatile("" : "+v"(cur[T]));
         __syncthreads();                            // also: the region is complete
         for (int it = 0; it < nin; ++it) {
             const int cb = it & 1;

@@ -598,3 +598,51 @@ def test_argmax_epilogue_in_the_lstm_kernels_equals_finalize_kernel(scorer, seed
         q0, q1 = qa[:, 0], qa[:, 1]
         assert np.array_equal(got["action"], np.argmax(qa, axis=1).astype(np.int32))
     assert np.array_equal(got["margin"], np.abs(q0 - q1))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 10))))
+def test_pingpong_wide_vae_kernel_equals_the_one_tile_kernel(scorer, seed):
+    """vae_wide16pp_kernel (two 64-window tiles per workgroup in ping-pong over one weight ring, persistent grid,
+    16-byte region loads) performs vae_wide16_kernel's MFMAs in the same order per accumulator: the reconstruction
+    error must be the same bit for bit — ragged batches (odd tile counts, tiles of fewer than 64 windows, series too
+    short for a window), with and without the RobustScaler transform, device MinMax, both window lags, hidden widths
+    97..128, D not a multiple of 32; and it is held to the oracle like every other kernel."""
+    rng = np.random.default_rng(7000 + seed)
+    Wn = int(rng.integers(4, 31))
+    F = int(rng.choice([6, 17, 38, 123]))
+    hid = int(rng.choice([97, 112, 128]))
+    D = Wn * F
+    if D <= 128:
+        F = 38
+        D = Wn * F
+    n_enc = 1 + seed % 2
+    vae = synth_vae(rng, [D] + [hid] * n_enc + [int(rng.choice([3, 10, 32])), hid, D], n_enc)
+    n_seg = int(rng.integers(1, 6))
+    lens = [int(rng.integers(max(1, Wn - 2), Wn + 400)) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = Wn + int(rng.integers(1, 700))
+    x = rng.random((sum(lens), F), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    kw = dict(vae_lag=int(seed % 3 != 0), want=("err",))
+    scaled = seed % 4 != 3
+    if scaled:
+        kw.update(vae_center=rng.uniform(0.3, 0.7, D), vae_scale=rng.uniform(0.05, 0.6, D), vae_clip=2.0)
+    if seed % 2:
+        kw.update(in_scale=rng.uniform(0.5, 2.0, n_seg).astype(np.float32), in_offset=rng.uniform(-0.5, 0.5, n_seg).astype(np.float32))
+    scorer.set_vae(vae)
+    with scorer.knob("vae_pp", 0):
+        ref = scorer.score(x, Wn, off, **kw)["err"]
+        assert scorer.vae_variant == "wide16"
+    with scorer.knob("vae_pp", 2):
+        got = scorer.score(x, Wn, off, **kw)["err"]
+        assert scorer.vae_variant == "wide16pp"
+    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (Wn, F, hid, lens, kw.keys())
+    # and against the oracle (first series that has windows)
+    i = next(i for i, n in enumerate(lens) if n > Wn)
+    xs = x[off[i]:off[i + 1]][:Wn + 120]
+    if "in_scale" in kw:
+        xs = (xs * kw["in_scale"][i] + kw["in_offset"][i]).astype(np.float32)
+    K0 = int(np.maximum(np.diff(off)[:i] - Wn, 0).sum())
+    lo = 1 - kw["vae_lag"]
+    X = orc.vae_windows_multivariate(xs, Wn, kw.get("vae_center"), kw.get("vae_scale"), 2.0 if scaled else None, lo, lo + len(xs) - Wn)
+    rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], dtype=np.float64)
+    np.testing.assert_allclose(got[K0:K0 + len(X)], orc.recon_error(X, rec, np.float64), rtol=RTOL)
