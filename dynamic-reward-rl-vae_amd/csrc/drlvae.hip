@@ -660,6 +660,11 @@ int drl_set_knob(drl_ctx* c, const char* name, long long v) {
     return DRL_OK;
 }
 
+#ifdef VW16_STAMPS
+int drl_debug_stamps16(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vw16_dbg), std::min<size_t>((size_t)n, 64 * 5) * sizeof(unsigned long long));
+}
+#endif
 #ifdef VWP_STAMPS
 int drl_debug_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vwp_dbg), std::min<size_t>((size_t)n, 2 * 64 * 3) * sizeof(unsigned long long));

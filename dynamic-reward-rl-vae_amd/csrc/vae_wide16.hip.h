@@ -19,6 +19,7 @@
 // so accumulator register r of row tile T is the B operand of the next layer's k-step (T, r), which
 // covers units 16T + 4q + r, q = 0..3: activations chain from layer to layer in the register file.
 #pragma once
+#include <type_traits>
 
 #define VW16_WIN 64          // windows per workgroup
 #define VW16_SLAB 4096       // floats per staged weight slab
@@ -32,6 +33,14 @@
 #define VW16_SYNC() do { } while (0)
 #else
 #define VW16_SYNC() __syncthreads()
+#endif
+
+// VW16_STAMPS (diagnostic builds): s_memtime stamps of layer 0's first slabs, workgroup 0, wave 0
+#ifdef VW16_STAMPS
+__device__ unsigned long long vw16_dbg[64 * 5];
+#define VW16_STAMP(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && it < 64) vw16_dbg[it * 5 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VW16_STAMP(i) do { } while (0)
 #endif
 
 struct Vae16Args {
@@ -50,13 +59,17 @@ __device__ __forceinline__ void act4(f32x4& v, int act) {
     else if (act == 2) { for (int r = 0; r < 4; ++r) v[r] = fast_sigmoid(v[r]); }
     else if (act == 3) { for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[r])); }
 }
-__device__ __forceinline__ void vw16_stage_load(f32x4 (&reg)[4], const float* __restrict__ src) {
+// `src` is the same for every thread (a slab of the weight pack): base + one of four per-thread byte offsets that never
+// change.  (A VALU instruction of a wave whose SIMD-mate is streaming fp32 MFMAs waits for the MFMA in flight almost
+// every time — ~50 cycles each, tools/pp_stamps.py — so a load phase wants as little address arithmetic as possible;
+// hipcc still builds the 64-bit vector address with four adds rather than the scalar-base form.)
+__device__ __forceinline__ void vw16_stage_load(f32x4 (&reg)[4], const float* __restrict__ src, const unsigned (&voff)[4]) {
 #if VW16_ABL == 3 || VW16_ABL == 11
     return;
 #endif
-    const f32x4* p = reinterpret_cast<const f32x4*>(src) + threadIdx.x;
+    const char* __restrict__ p = reinterpret_cast<const char*>(src);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) reg[i] = p[i * 256];
+    for (int i = 0; i < 4; ++i) reg[i] = *reinterpret_cast<const f32x4*>(p + voff[i]);
 }
 __device__ __forceinline__ void vw16_stage_store(const f32x4 (&reg)[4], float* dst) {
 #if VW16_ABL == 5 || VW16_ABL == 11
@@ -83,6 +96,8 @@ __device__ __forceinline__ float vw16_epilogue(const f32x4& acc, const float (&x
     return sq;
 }
 
+// (A 168-register build, three workgroups per CU where their LDS fits — SMD-sized regions — spills 25 registers and
+// measured 0.186 ms against 0.175 ms on C3: not kept.)
 template <bool SCALED>
 __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
     extern __shared__ __attribute__((aligned(16))) float vw16_smem[];
@@ -96,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
     const int tile = blockIdx.x;                    // < a.n_tiles by construction of the grid
 
     f32x4 stg[4];
-    vw16_stage_load(stg, b.w16[0]);                 // layer 0's first slab: in flight while the windows are staged
+    const unsigned voff[4] = {threadIdx.x * 16u, threadIdx.x * 16u + 4096u, threadIdx.x * 16u + 8192u, threadIdx.x * 16u + 12288u};
+    vw16_stage_load(stg, b.w16[0], voff);           // layer 0's first slab: in flight while the windows are staged
 
     // ---- this workgroup's 64 windows: stage the flat region they span, once
     const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
@@ -147,10 +163,11 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
         // side tile of a slab, layer 0: the four scaler tables, each slab of 32 columns transposed to [q][ks]
         // (position q*8 + ks holds column 4*ks + q) so that a lane's eight k-steps are two 16-byte reads;
         // every thread below 128 owns one position of one table and streams it slab by slab
-        const float* __restrict__ ss = (SCALED && threadIdx.x < 128)
-            ? a.rs + (size_t)(threadIdx.x >> 5) * a.rsP + 4 * (threadIdx.x & 7) + ((threadIdx.x & 31) >> 3) : w;
+        const bool side_thr = SCALED && threadIdx.x < 128;
+        const unsigned soff = side_thr ? (unsigned)(((size_t)(threadIdx.x >> 5) * a.rsP + 4 * (threadIdx.x & 7) + ((threadIdx.x & 31) >> 3)) * 4) : 0u;
+        const char* __restrict__ rsb = reinterpret_cast<const char*>(SCALED ? a.rs : w);      // the same for every thread
         vw16_stage_store(stg, wt);
-        if (SCALED && threadIdx.x < 128) side[threadIdx.x] = ss[0];
+        if (side_thr) side[threadIdx.x] = *reinterpret_cast<const float*>(rsb + soff);
         // The biases above came from global memory.  Unless they are consumed HERE, the compiler's wait-count pass
         // keeps "cur[T] may still be in flight" alive around the loop's back edge and puts s_waitcnt vmcnt(7..0) in
         // front of the first eight MFMAs of EVERY slab — which then also wait for the loads of the next slab issued
@@ -158,18 +175,25 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
 #pragma unroll
         for (int T = 0; T < 8; ++T) asm volatile("" : "+v"(cur[T]));
         __syncthreads();                            // also: the region is complete
-        for (int it = 0; it < nin; ++it) {
-            const int cb = it & 1;
+        // Every address of the loop is a value that never changes plus a compile-time offset (the ring buffer index
+        // is the unrolled iteration's parity) or a scalar (the slab's base): a slab costs ONE vector instruction
+        // besides its loads, MFMAs and the input transform (the walk of xt).
+        const float* __restrict__ wl = wt + lane * 4;           // this lane's A fragments inside a ring buffer
+        const float* __restrict__ sl = side + q * 8;
+        float* const sdw = side + threadIdx.x;
+        const float* __restrict__ xt = xw + q;
+        auto slab = [&](auto CBt, int it) __attribute__((always_inline)) {
+            constexpr int cb = decltype(CBt)::value;
             const bool more = it + 1 < nin;
             float side_next = 0.0f;
+            VW16_STAMP(0);
             if (more) {
-                if (SCALED) side_next = ss[(it + 1) * 32];
-                vw16_stage_load(stg, w + (size_t)(it + 1) * VW16_SLAB);
+                if (side_thr) side_next = *reinterpret_cast<const float*>(rsb + (size_t)(it + 1) * 128 + soff);
+                vw16_stage_load(stg, w + (size_t)(it + 1) * VW16_SLAB, voff);
             }
             if (active) {
-                const float* __restrict__ wb = wt + cb * VW16_SLAB + lane * 4;
-                const float* __restrict__ sb = side + cb * VW16_SIDE + q * 8;
-                const float* __restrict__ xt = xw + it * 32 + q;
+                const float* __restrict__ wb = wl + cb * VW16_SLAB;
+                const float* __restrict__ sb = sl + cb * VW16_SIDE;
                 // LDS reads in two batches, each requested before the MFMAs of the batch before it: the
                 // compiler left to itself reads four fragments and waits for them, every 16 MFMAs
                 f32x4 av[16], sc[4][2];
@@ -189,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
 #pragma unroll
                 for (int T = 0; T < 8; ++T) av[T * 2 + 1] = VW16_ABL >= 10 ? f32x4{xv[4], xv[5], xv[6], xv[7]} : *reinterpret_cast<const f32x4*>(wb + (T * 2 + 1) * 256);
                 __builtin_amdgcn_sched_barrier(0);
+                VW16_STAMP(1);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     float bv = xv[ks];
@@ -199,12 +224,22 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
                     if (ks == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            xt += 32;
+            VW16_STAMP(2);
             if (more) {
                 vw16_stage_store(stg, wt + (cb ^ 1) * VW16_SLAB);
-                if (SCALED && threadIdx.x < 128) side[(cb ^ 1) * VW16_SIDE + threadIdx.x] = side_next;
+                if (side_thr) sdw[(cb ^ 1) * VW16_SIDE] = side_next;
             }
+            VW16_STAMP(3);
             VW16_SYNC();
+            VW16_STAMP(4);
+        };
+        int it = 0;
+        for (; it + 1 < nin; it += 2) {
+            slab(std::integral_constant<int, 0>{}, it);
+            slab(std::integral_constant<int, 1>{}, it + 1);
         }
+        if (it < nin) slab(std::integral_constant<int, 0>{}, it);
 #pragma unroll
         for (int T = 0; T < 8; ++T) act4(cur[T], a.act[0]);
     }
@@ -215,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
     // them into it with every load in flight, and the fragments come from LDS.  The last layer's first slab
     // is requested before, and lands in registers meanwhile.
     const int last = a.n - 1;
-    vw16_stage_load(stg, b.w16[last]);
+    vw16_stage_load(stg, b.w16[last], voff);
     const bool mid_lds = b.mid_floats > 0;
     if (mid_lds) {
         const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(b.w16[1]);
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
                                 nxt[ot] = mfma16x4(w[(((size_t)ot * nin + Tin) * 4 + r) * 64 + lane], cur[Tin][r], nxt[ot]);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);      // one input tile's fragments in flight at a time
             }
 #pragma unroll
             for (int ot = 0; ot < 8; ++ot) { cur[ot] = nxt[ot]; act4(cur[ot], a.act[p]); }
@@ -274,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16_kernel(VaeArgs a, Vae16Args
             float side_next = 0.0f;
             if (more) {
                 side_next = ss[(ot + 1) * 32];
-                vw16_stage_load(stg, w + (size_t)(ot + 1) * VW16_SLAB);
+                vw16_stage_load(stg, w + (size_t)(ot + 1) * VW16_SLAB, voff);
             }
             if (active) {
                 const float* __restrict__ wb = wt + cb * VW16_SLAB + lane * 4;
