@@ -682,7 +682,7 @@ struct RecArgs {
 #endif
 #ifndef REC_ABL
 #define REC_ABL 0     // timing-only ablations (wrong results): 1 no projection refill, 2 no cell update, 3 no flag term, 4 = 1+2,
-                      // 5 (rec2) no LDS reads of A fragments
+                      // 5 (rec2) no LDS reads of A fragments, 6 (rec2) the refills touch only gate tiles 0..3: half the L2 footprint
 #endif
 template <int NT>
 __device__ __forceinline__ f32x16 rec_load_p(const char* __restrict__ P, size_t chunk_bytes, unsigned voff, int tl) {
@@ -844,7 +844,11 @@ __device__ __forceinline__ void rec_step2(f32x16 (&pq)[REC_RING], float (&aq)[2]
 #pragma unroll
     for (int tl = 0; tl < NT; ++tl) {
         f32x16 acc0 = pq[tl % REC_RING], acc1;
-#if REC_ABL != 1 && REC_ABL != 4
+#if REC_ABL == 6
+        // half the footprint, the same loads: every refill reads one of gate tiles 0..3 (16 KiB per wave and step)
+        pq[tl % REC_RING] = (tl + REC_RING < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, (tl + REC_RING) & 3)
+                                   : rec_load_p<NT>(Pb, chunk_bytes, voff_n, (tl + REC_RING - NT) & 3);
+#elif REC_ABL != 1 && REC_ABL != 4
         pq[tl % REC_RING] = (tl + REC_RING < NT) ? rec_load_p<NT>(Pb, chunk_bytes, voff_t, tl + REC_RING)
                                    : rec_load_p<NT>(Pb, chunk_bytes, voff_n, tl + REC_RING - NT);
 #endif
