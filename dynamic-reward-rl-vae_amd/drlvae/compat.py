@@ -193,10 +193,26 @@ class RewardFunction:
         self.label_column = label_column
         self._cache: Dict[tuple, np.ndarray] = {}
         self.max_cached_series = 256
+        self._last = None          # (values the errors were computed from, errors, vae identity) of the last series
 
     def clear(self):
         """Forget every cached series (call after re-training the VAE in place)."""
         self._cache.clear()
+        self._last = None
+
+    def error_at(self, timeseries, c: int) -> float:
+        """The reconstruction error of the window the reward at cursor ``c`` looks at, v[c-W : c].  The reference
+        calls the reward function at every env.step; hashing the whole series each time (errors_for) would make
+        the cache lookup O(N) per step.  The error depends on those W values only, so the per-step path compares
+        just them with the series the last lookup scored — O(W), and exact: a different series, or one edited in
+        place inside the window, falls through to the content-keyed lookup."""
+        W = self.W
+        col = np.asarray(timeseries["value"])                       # a view for ndarray / pandas columns
+        last = self._last
+        if last is not None and last[2] == (id(self.vae), id(self.vae.config)) and len(col) == len(last[0]) \
+                and np.array_equal(np.asarray(col[c - W:c], dtype=np.float32), last[0][c - W:c]):
+            return float(last[1][c - W])
+        return float(self.errors_for(timeseries)[c - W])
 
     def errors_for(self, timeseries) -> np.ndarray:
         # keyed on the CONTENT of the value column (length + a hash of its bytes) and on the VAE the errors
@@ -210,13 +226,14 @@ class RewardFunction:
             if len(self._cache) >= self.max_cached_series:
                 self._cache.pop(next(iter(self._cache)))            # oldest entry
             self._cache[key] = err
+        self._last = (v.copy(), err, (id(self.vae), id(self.vae.config)))      # a copy: v may alias the caller's column
         return err
 
     def __call__(self, timeseries, timeseries_curser, action=0, vae=None, dynamic_coef=1.0):
         c = timeseries_curser
         if c < self.W:
             return [0, 0]
-        pen = dynamic_coef * float(self.errors_for(timeseries)[c - self.W]) if self.include else 0.0
+        pen = dynamic_coef * self.error_at(timeseries, c) if self.include else 0.0
         lab = timeseries[self.label_column][c]
         if lab == 0:
             return [self.tn + pen, self.fp + pen]

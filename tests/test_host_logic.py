@@ -334,7 +334,7 @@ def test_reward_function_cache_is_keyed_on_content():
 
         def score(self, v, W, **kw):
             FakeScorer.calls += 1
-            return {"err": np.asarray(v[W:], np.float32) * 2}
+            return {"err": np.asarray(v[W - 1:-1], np.float32) * 2}      # err[k] = 2 * last value of the window v[k : k+W]
 
     class FakeVae:
         config = {}
@@ -346,14 +346,25 @@ def test_reward_function_cache_is_keyed_on_content():
     rf = compat.RewardFunction(FakeVae(), 3)
     a = {"value": np.arange(10, dtype=np.float32), "label": np.zeros(10)}
     r1 = rf(a, 5, 0, dynamic_coef=1.0)
-    assert FakeScorer.calls == 1 and r1 == [1.0 + 10.0, -1.0 + 10.0]
+    assert FakeScorer.calls == 1 and r1 == [1.0 + 8.0, -1.0 + 8.0]
     rf(dict(a), 6, 0)                                   # another object, same content: no new scoring call
     assert FakeScorer.calls == 1
-    a["value"][5] = 100.0                               # edited in place: must not return the stale error
-    assert rf(a, 5, 0, dynamic_coef=1.0) == [1.0 + 200.0, -1.0 + 200.0] and FakeScorer.calls == 2
+    # the per-step path: consecutive cursors of the same series compare W values, they do not hash the series
+    hashed = []
+    orig = rf.errors_for
+    rf.errors_for = lambda ts: (hashed.append(1), orig(ts))[1]
+    for c in range(3, 10):
+        assert rf(a, c, 0, dynamic_coef=1.0)[0] == 1.0 + 2.0 * (c - 1)
+    assert hashed == [] and FakeScorer.calls == 1
+    a["value"][4] = 100.0                               # edited in place inside the window: never the stale error
+    assert rf(a, 5, 0, dynamic_coef=1.0) == [1.0 + 200.0, -1.0 + 200.0] and FakeScorer.calls == 2 and hashed == [1]
+    assert rf(a, 9, 0, dynamic_coef=1.0)[0] == 1.0 + 16.0 and FakeScorer.calls == 2       # the edit is outside this window
+    b = {"value": np.arange(10, dtype=np.float32)[::-1].copy(), "label": np.zeros(10)}
+    assert rf(b, 5, 0, dynamic_coef=1.0)[0] == 1.0 + 2.0 * 5.0 and FakeScorer.calls == 3   # another series of the same length
+    rf.errors_for = orig
     rf.clear()
     rf(a, 5, 0)
-    assert FakeScorer.calls == 3
+    assert FakeScorer.calls == 4
 
 
 def test_tf_bundle_reader_on_every_reference_checkpoint():
