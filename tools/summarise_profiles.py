@@ -7,13 +7,13 @@ src, dst = "gpurun_out/round", f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(f"{src}/bench_*.json"):
     shutil.copy(f, dst)
-for w in ("c2", "c4"):
+for w in ("c2", "c3", "c4"):
     fs = sorted(glob.glob(f"{src}/trace_{w}/*/*kernel_stats.csv"), key=os.path.getmtime)
     if fs:                                  # gpurun merges results: older runs may still lie beside the newest
         shutil.copy(fs[-1], f"{dst}/{w}_kernel_stats.csv")
-for w in ("c2", "c4"):
+for w in ("c2", "c3", "c4"):
     out = {"workload": w,
-           "command": f"rocprofv3 --pmc <group> --output-format csv -- python bench.py --workload {w} --steps 5 --warmup 1 --no-cpu-baseline (one run per counter group, tools/profile_round.sh)",
+           "command": f"rocprofv3 --pmc <group> --output-format csv -- python bench.py --workload {w} --steps 5 --warmup 1 --no-cpu-baseline --no-alt --no-others (one run per counter group, so one launch population per kernel; tools/profile_round.sh)",
            "note": "per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a wide coalesced read stream, so hbm_read_bytes = 2*FETCH_SIZE*1024 (an upper bound for these kernels' dword loads); WRITE_SIZE is exact.",
            "kernels": {}}
     for d in ("sq", "fetch", "write", "inst"):
