@@ -6,6 +6,7 @@
 #include "lstm_w16.hip.h"
 #include "vae_wide16.hip.h"
 #include "vae_wide16pp.hip.h"
+#include "vae_wide16s.hip.h"
 
 #include <hipcub/hipcub.hpp>
 #include <dlfcn.h>
@@ -127,6 +128,8 @@ struct drl_ctx {
     bool no_pipeline = false;     // host path: always the one-shot copy
     bool no_fused_epilogue = false;   // action / margin always by finalize_kernel
     bool rollout_dense = false;   // drl_rollout_batch: full passes only
+    int vae_s = 1;                // wide windows: the software-pipelined kernel (vae_wide16s.hip.h): 0 never, 1 when two of its
+                                  // workgroups fit a CU's LDS (measured faster then, slower alone), 2 whenever one fits
     int vae_pp = 0;               // wide windows: the ping-pong kernel (two tiles per workgroup, persistent): 0 never (default:
                                   // measured slower than vae_wide16_kernel), 1 calls of more 64-window
                                   // tiles than CUs, 2 whenever its LDS fits
@@ -559,6 +562,8 @@ int drl_create(int device_id, drl_ctx** out) {
             attr(reinterpret_cast<const void*>(vae_kernel<DRL_VAE_MAX_TILES, true>), CHAIN_LDS_MAX) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<false>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<true>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<false>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<false>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>), 160 * 1024) &&
@@ -575,7 +580,7 @@ int drl_create(int device_id, drl_ctx** out) {
     }
     // the environment is read here and nowhere else
     for (const char* name : {"force_generic", "overlap", "rec2", "rollout", "gemv_rounds", "vw16_pad", "rec_lds_pad", "pbuf_max",
-                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense", "vae_pp"}) {
+                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense", "vae_pp", "vae_s"}) {
         std::string var = "DRLVAE_";
         for (const char* p = name; *p; ++p) var += (char)toupper((unsigned char)*p);
         if (const char* e = getenv(var.c_str())) (void)drl_set_knob(c, name, atoll(e));
@@ -655,6 +660,7 @@ int drl_set_knob(drl_ctx* c, const char* name, long long v) {
     else if (n == "no_pipeline") c->no_pipeline = v != 0;
     else if (n == "no_fused_epilogue") c->no_fused_epilogue = v != 0;
     else if (n == "rollout_dense") c->rollout_dense = v != 0;
+    else if (n == "vae_s") c->vae_s = (int)v;
     else if (n == "vae_pp") c->vae_pp = (int)std::min<long long>(2, std::max<long long>(0, v));
     else return fail(c, DRL_ERR_ARG, "drl_set_knob: unknown knob '%s'", name);
     return DRL_OK;
@@ -663,6 +669,11 @@ int drl_set_knob(drl_ctx* c, const char* name, long long v) {
 #ifdef VW16_STAMPS
 int drl_debug_stamps16(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vw16_dbg), std::min<size_t>((size_t)n, 64 * 5) * sizeof(unsigned long long));
+}
+#endif
+#ifdef VWS_STAMPS
+int drl_debug_stamps_s(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vws_dbg), std::min<size_t>((size_t)n, 64 * 4) * sizeof(unsigned long long));
 }
 #endif
 #ifdef VWP_STAMPS
@@ -1159,12 +1170,17 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         const int xr_pp = xr_floats + 4;
         const size_t pp_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)2 * xr_pp) * sizeof(float);
         const bool use_pp = wide && pp_wanted && pp_lds <= 160 * 1024;
+        const size_t s_lds = ((size_t)VWS_RING * VW16_SLAB + VWS_RING * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
         if (prof) prof_begin(c, 1, vst);
         if (wide) {
             if (wide_lds > c->wide_lds_set) {
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
@@ -1192,6 +1208,11 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 if (a.rs) hipLaunchKernelGGL(vae_wide16pp_kernel<true>, grid, dim3(VWP_THREADS), pp_lds, vst, a, b16, xr_pp);
                 else hipLaunchKernelGGL(vae_wide16pp_kernel<false>, grid, dim3(VWP_THREADS), pp_lds, vst, a, b16, xr_pp);
                 c->last_vae_variant = "wide16pp";
+            } else if ((c->vae_s == 1 && 2 * s_lds <= 160 * 1024) || (c->vae_s >= 2 && s_lds <= 160 * 1024)) {
+                const dim3 grid(sh.tiles64);         // a workgroup = one tile, one workgroup per CU
+                if (a.rs) hipLaunchKernelGGL(vae_wide16s_kernel<true>, grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                else hipLaunchKernelGGL(vae_wide16s_kernel<false>, grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                c->last_vae_variant = "wide16s";
             } else {
                 const dim3 grid(sh.tiles64);         // a workgroup = one tile
                 if (a.rs) hipLaunchKernelGGL(vae_wide16_kernel<true>, grid, dim3(256), wide_lds, vst, a, b16, xr_floats);

@@ -44,7 +44,7 @@ def test_default_line_has_the_contract_fields():
             assert key in c, key
         assert 0 < c["frac"] < 1 and 0 < c["frac_alone"] < 1 and c["value"] > 1e6
     assert oc["C5"]["timed_region_s"] >= 0.8 and oc["C5"]["windows_per_step"] == 4_000_000     # a sustained leg
-    assert oc["C3"]["lstm_kernel"] == oc["C4"]["lstm_kernel"] == "xproj+rec" and oc["C4"]["vae_kernel"] == "wide16"
+    assert oc["C3"]["lstm_kernel"] == oc["C4"]["lstm_kernel"] == "xproj+rec" and oc["C4"]["vae_kernel"] == "wide16s"
     assert 0 < oc["C4"]["vae_frac_alone"] < 1
     hp = {h["workload"][:2]: h for h in d["host_path"]}
     assert sorted(hp) == ["C2", "C4"] and all(h["value"] > 1e6 and h["ms_per_call"] > 0 for h in hp.values())

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 # the suite runs every time)
 N_UNI = int(os.environ.get("DRLVAE_SWEEP_SEEDS", 16))
 N_MULTI = int(os.environ.get("DRLVAE_SWEEP_SEEDS", 12))
+VAE_S_DEFAULT = 1          # the library's default of the vae_s knob
 
 
 @pytest.fixture(scope="module")
@@ -601,10 +602,11 @@ def test_argmax_epilogue_in_the_lstm_kernels_equals_finalize_kernel(scorer, seed
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 10))))
-def test_pingpong_wide_vae_kernel_equals_the_one_tile_kernel(scorer, seed):
-    """vae_wide16pp_kernel (two 64-window tiles per workgroup in ping-pong over one weight ring, persistent grid,
-    16-byte region loads) performs vae_wide16_kernel's MFMAs in the same order per accumulator: the reconstruction
-    error must be the same bit for bit — ragged batches (odd tile counts, tiles of fewer than 64 windows, series too
+def test_wide_vae_kernel_variants_equal_the_one_tile_kernel(scorer, seed):
+    """vae_wide16s_kernel (software-pipelined: every memory operation of a slab behind an MFMA of the slab before; the
+    default where two of its workgroups fit a CU) and vae_wide16pp_kernel (two 64-window tiles per workgroup in
+    ping-pong over one weight ring, persistent grid, 16-byte region loads; opt-in) perform vae_wide16_kernel's MFMAs in
+    the same order per accumulator: the reconstruction error must be the same bit for bit — ragged batches (odd tile counts, tiles of fewer than 64 windows, series too
     short for a window), with and without the RobustScaler transform, device MinMax, both window lags, hidden widths
     97..128, D not a multiple of 32; and it is held to the oracle like every other kernel."""
     rng = np.random.default_rng(7000 + seed)
@@ -629,13 +631,17 @@ def test_pingpong_wide_vae_kernel_equals_the_one_tile_kernel(scorer, seed):
     if seed % 2:
         kw.update(in_scale=rng.uniform(0.5, 2.0, n_seg).astype(np.float32), in_offset=rng.uniform(-0.5, 0.5, n_seg).astype(np.float32))
     scorer.set_vae(vae)
-    with scorer.knob("vae_pp", 0):
+    with scorer.knob("vae_pp", 0), scorer.knob("vae_s", 0, restore=VAE_S_DEFAULT):
         ref = scorer.score(x, Wn, off, **kw)["err"]
         assert scorer.vae_variant == "wide16"
     with scorer.knob("vae_pp", 2):
         got = scorer.score(x, Wn, off, **kw)["err"]
         assert scorer.vae_variant == "wide16pp"
     assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (Wn, F, hid, lens, kw.keys())
+    with scorer.knob("vae_s", 2, restore=VAE_S_DEFAULT):
+        got_s = scorer.score(x, Wn, off, **kw)["err"]
+        assert scorer.vae_variant == "wide16s"
+    assert np.array_equal(ref.view(np.uint32), got_s.view(np.uint32)), ("wide16s", Wn, F, hid, lens, kw.keys())
     # and against the oracle (first series that has windows)
     i = next(i for i, n in enumerate(lens) if n > Wn)
     xs = x[off[i]:off[i + 1]][:Wn + 120]

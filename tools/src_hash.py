@@ -7,7 +7,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["include/drlvae.h"] + ["dynamic-reward-rl-vae_amd/csrc/" + f for f in
-                                ("drlvae.hip", "kernels.hip.h", "lstm_f16x3.hip.h", "lstm_w16.hip.h", "vae_wide16.hip.h", "vae_wide16pp.hip.h")]
+                                ("drlvae.hip", "kernels.hip.h", "lstm_f16x3.hip.h", "lstm_w16.hip.h", "vae_wide16.hip.h", "vae_wide16pp.hip.h", "vae_wide16s.hip.h")]
 
 
 def src_hash(root=ROOT):

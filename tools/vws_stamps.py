@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Diagnostic (needs a -DVWS_STAMPS build, DRLVAE_LIB=...): s_memtime stamps of vae_wide16s_kernel's layer-0 slabs for
+wave 0 of workgroup 0: transform + LDS reads issued + first-half MFMAs | reads, stores, requests + second half | barrier."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-reward-rl-vae_amd")]
+import bench
+from drlvae.scorer import WindowScorer
+wl = bench.workload("c4", 0, int(sys.argv[1]) if len(sys.argv) > 1 else 32768)
+sc = WindowScorer(0)
+sc.set_vae(wl["vae"])
+sc.set_knob("vae_s", 1)
+kw = {k: v for k, v in wl["kw"].items() if k.startswith("vae")}
+for _ in range(3):
+    sc.score(wl["series"], wl["W"], wl["offsets"], want=("err",), **kw)
+assert sc.vae_variant == "wide16s", sc.vae_variant
+buf = (C.c_ulonglong * 256)()
+sc._lib.drl_debug_stamps_s.argtypes = [C.c_void_p, C.c_int]
+assert sc._lib.drl_debug_stamps_s(buf, 256) == 0
+t = np.array(buf, dtype=np.uint64).reshape(64, 4).astype(np.int64)
+for it in range(2, 20):
+    r = t[it]
+    print(f"slab {it:2d}: first half {r[1]-r[0]:5d}  second half {r[2]-r[1]:5d}  barrier {r[3]-r[2]:5d}  | slab total {t[it+1][0]-r[0]:5d}")
+print("mean cycles per slab", float(np.diff(t[2:60, 0]).mean()))
