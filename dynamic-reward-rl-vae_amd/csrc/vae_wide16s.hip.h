@@ -26,8 +26,10 @@
 
 #ifdef VWS_STAMPS
 __device__ unsigned long long vws_dbg[64 * 4];
-#define VWS_STAMP(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && it < 64) vws_dbg[it * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VWS_STAMP(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && it < 60) vws_dbg[it * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VWS_MARK(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0) vws_dbg[240 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define VWS_MARK(i) do { } while (0)
 #define VWS_STAMP(i) do { } while (0)
 #endif
 
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
     vw16_stage_load(stg, b.w16[0], voff);                   // layer 0's first two slabs: in flight while the windows are staged
     if (a.din[0] > 32) vw16_stage_load(stg2, b.w16[0] + VW16_SLAB, voff);
 
+    VWS_MARK(0);
     // ---- this workgroup's 64 windows: stage the flat region they span, once
     const int s = find_seg(a.seg.tile_off, a.seg.n_seg, tile);
     const long long samp0 = a.seg.samp_off[s];
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             }
         }
     }
+    VWS_MARK(1);
     int count = count_wg - 16 * wave;
     count = count < 0 ? 0 : (count > 16 ? 16 : count);
     const int jc = col < count ? col : (count > 0 ? count - 1 : 0);
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
         };
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) transform(ks);
+        VWS_MARK(2);
         int rb = 0;                                         // ring buffer of slab it
         const float* __restrict__ wp = w + 3 * VW16_SLAB;   // slab it+3
         const float* __restrict__ sp = ss + 3 * 32;
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             VWS_STAMP(3);
             rb = rn;
         }
+        VWS_MARK(3);
 #pragma unroll
         for (int T = 0; T < 8; ++T) act4(cur[T], a.act[0]);
     }
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
         for (int ot = 0; ot < 8; ++ot) { cur[ot] = nxt[ot]; act4(cur[ot], a.act[p]); }
     }
     if (mid_lds) __syncthreads();                           // the ring is rewritten below
+    VWS_MARK(4);
 
     // ---- last layer: hidden -> D, weights streamed per 32-element output slab, error fused
     float sq = 0.0f;
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
                                              : xv[T2 * 4 + r];
         };
         transform();
+        VWS_MARK(5);
         int rb = 0;
         const float* __restrict__ wp = w + 3 * VW16_SLAB;   // slab ot+3
         const float* __restrict__ sp = ss + 3 * 32;
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             rb = rn;
         }
     }
+    VWS_MARK(6);
     sq += __shfl_xor(sq, 16);                               // the four q of a window hold different rows
     sq += __shfl_xor(sq, 32);
     if (a.err && q == 0 && col < count) a.err[wout] = sq / (float)D;

@@ -299,6 +299,10 @@ int drl_last_call_overlapped(drl_ctx* ctx);
  *   pipe_min bytes, pipe_chunk samples, no_pipeline 0|1    the pipelined host path of drl_score_batch
  *   no_fused_epilogue 0|1  action / margin always by finalize_kernel
  *   rollout_dense 0|1      drl_rollout_batch: full passes only
+ *   vae_s 0|1|2            wide windows: the software-pipelined kernel (vae_wide16s_kernel) never | where two of its
+ *                          workgroups fit a CU's LDS (default) | wherever one fits; else vae_wide16_kernel (same bits)
+ *   vae_pp 0|1|2           wide windows: the ping-pong kernel (vae_wide16pp_kernel; same bits, measured slower):
+ *                          never (default) | from a full round of tile pairs | always
  * Unknown names: DRL_ERR_ARG. */
 int drl_set_knob(drl_ctx* ctx, const char* name, long long value);
 /* How many times the library has asked the HIP runtime (or RCCL) for a resource since it was loaded: device or

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-reward-rl-vae_amd")]
 import bench
 from drlvae.scorer import WindowScorer
-wl = bench.workload("c4", 0, int(sys.argv[1]) if len(sys.argv) > 1 else 32768)
+wl = bench.workload(sys.argv[2] if len(sys.argv) > 2 else "c4", 0, int(sys.argv[1]) if len(sys.argv) > 1 else 32768)
 sc = WindowScorer(0)
 sc.set_vae(wl["vae"])
 sc.set_knob("vae_s", 1)
@@ -19,7 +19,12 @@ buf = (C.c_ulonglong * 256)()
 sc._lib.drl_debug_stamps_s.argtypes = [C.c_void_p, C.c_int]
 assert sc._lib.drl_debug_stamps_s(buf, 256) == 0
 t = np.array(buf, dtype=np.uint64).reshape(64, 4).astype(np.int64)
-for it in range(2, 20):
+for it in range(2, 8):
     r = t[it]
     print(f"slab {it:2d}: first half {r[1]-r[0]:5d}  second half {r[2]-r[1]:5d}  barrier {r[3]-r[2]:5d}  | slab total {t[it+1][0]-r[0]:5d}")
-print("mean cycles per slab", float(np.diff(t[2:60, 0]).mean()))
+print("mean cycles per slab", float(np.diff(t[2:59, 0]).mean()))
+m = np.array(buf, dtype=np.uint64).astype(np.int64)[240:247]
+names = ["region staged", "layer-0 prologue", "layer-0 loop", "act + middle layers", "last-layer prologue", "last-layer loop"]
+for i, nm in enumerate(names):
+    print(f"{nm:22s} {m[i+1]-m[i]:8d} cycles")
+print("total", m[6] - m[0])
