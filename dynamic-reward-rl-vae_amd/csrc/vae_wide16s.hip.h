@@ -33,6 +33,19 @@ __device__ unsigned long long vws_dbg[64 * 4];
 #define VWS_STAMP(i) do { } while (0)
 #endif
 
+// robust_apply (kernels.hip.h) on two columns at once: the same IEEE operations per element, as packed fp32
+// instructions (v_pk_add/mul/fma_f32: two floats per lane per issue; 40 -> 30 VALU instructions per slab as compiled).
+// VALU and fp32 MFMA share the SIMD's pipe, so every VALU cycle is a cycle without an MFMA; measured, though, the
+// 10 instructions of ~200 per slab pair are within the noise of the kernel's time (2.42 / 2.44 ms on C4).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 robust_apply2(f32x2 x, f32x2 c_hi, f32x2 c_lo, f32x2 i_hi, f32x2 i_lo, float clip) {
+    f32x2 t = x - c_hi;
+    t = t - c_lo;
+    const f32x2 p = t * i_lo;
+    const f32x2 r = __builtin_elementwise_fma(t, i_hi, p);
+    return f32x2{__builtin_amdgcn_fmed3f(r[0], -clip, clip), __builtin_amdgcn_fmed3f(r[1], -clip, clip)};
+}
+
 template <bool SCALED>
 __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
     extern __shared__ __attribute__((aligned(16))) float vws_smem[];
@@ -139,12 +152,20 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
         }
 #pragma unroll
         for (int T = 0; T < 8; ++T) av[T * 2] = *reinterpret_cast<const f32x4*>(wl + (T * 2) * 256);
-        auto transform = [&](int ks) __attribute__((always_inline)) {
-            bv[ks] = SCALED ? robust_apply(xv[ks], sc[0][ks >> 2][ks & 3], sc[1][ks >> 2][ks & 3], sc[2][ks >> 2][ks & 3],
-                                           sc[3][ks >> 2][ks & 3], clip) : xv[ks];
+        auto transform = [&](int kp) __attribute__((always_inline)) {      // columns 2kp and 2kp+1 of the slab
+            const int ks = 2 * kp, h = ks >> 2, e = ks & 3;
+            if (SCALED) {
+                const f32x2 r = robust_apply2(f32x2{xv[ks], xv[ks + 1]}, f32x2{sc[0][h][e], sc[0][h][e + 1]}, f32x2{sc[1][h][e], sc[1][h][e + 1]},
+                                              f32x2{sc[2][h][e], sc[2][h][e + 1]}, f32x2{sc[3][h][e], sc[3][h][e + 1]}, clip);
+                bv[ks] = r[0];
+                bv[ks + 1] = r[1];
+            } else {
+                bv[ks] = xv[ks];
+                bv[ks + 1] = xv[ks + 1];
+            }
         };
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) transform(ks);
+        for (int kp = 0; kp < 4; ++kp) transform(kp);
         VWS_MARK(2);
         int rb = 0;                                         // ring buffer of slab it
         const float* __restrict__ wp = w + 3 * VW16_SLAB;   // slab it+3
@@ -197,13 +218,11 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
                     else if (n < 12) *reinterpret_cast<f32x4*>(stp + (n - 8) * 1024) = stg[n - 8];
                     else if (n == 12) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
                     else if (n == 13) { vw16_stage_load(stg, wp, voff); if (side_thr) side_next = sp[0]; }
-                    else if (n >= 16 && n < 20) transform(n - 16);
-                    else if (n == 20) transform(4);         // (ks 4 was used by MFMAs 0..7 of this half)
-                    else if (n == 21) transform(5);         // (ks 5: MFMAs 8..15)
-                    else if (n == 24) transform(6);         // (ks 6: MFMAs 16..23)
+                    else if (n == 16 || n == 17) transform(n - 16);     // (ks 0..3: the first half's)
+                    else if (n == 18) transform(2);         // (ks 4, 5 were used by MFMAs 0..15 of this half)
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            transform(7);
+            transform(3);                                   // (ks 6, 7: by MFMAs 16..31)
             wp += VW16_SLAB;
             sp += 32;
             __builtin_amdgcn_sched_barrier(0);
@@ -315,9 +334,18 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
 #pragma unroll
             for (int T2 = 0; T2 < 2; ++T2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xt8[T2 * 4 + r] = SCALED ? robust_apply(xv[T2 * 4 + r], sc[T2][0][r], sc[T2][1][r], sc[T2][2][r], sc[T2][3][r], clip)
-                                             : xv[T2 * 4 + r];
+                for (int r = 0; r < 4; r += 2) {
+                    if (SCALED) {
+                        const f32x2 t = robust_apply2(f32x2{xv[T2 * 4 + r], xv[T2 * 4 + r + 1]}, f32x2{sc[T2][0][r], sc[T2][0][r + 1]},
+                                                      f32x2{sc[T2][1][r], sc[T2][1][r + 1]}, f32x2{sc[T2][2][r], sc[T2][2][r + 1]},
+                                                      f32x2{sc[T2][3][r], sc[T2][3][r + 1]}, clip);
+                        xt8[T2 * 4 + r] = t[0];
+                        xt8[T2 * 4 + r + 1] = t[1];
+                    } else {
+                        xt8[T2 * 4 + r] = xv[T2 * 4 + r];
+                        xt8[T2 * 4 + r + 1] = xv[T2 * 4 + r + 1];
+                    }
+                }
         };
         transform();
         VWS_MARK(5);
