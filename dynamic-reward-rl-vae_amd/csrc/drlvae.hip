@@ -671,6 +671,11 @@ int drl_debug_stamps16(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vw16_dbg), std::min<size_t>((size_t)n, 64 * 5) * sizeof(unsigned long long));
 }
 #endif
+#ifdef DRL_CLK_STAMPS
+int drl_debug_clock(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(drl_clk_dbg), 4 * sizeof(unsigned long long));
+}
+#endif
 #ifdef VWS_STAMPS
 int drl_debug_stamps_s(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vws_dbg), std::min<size_t>((size_t)n, 64 * 4) * sizeof(unsigned long long));

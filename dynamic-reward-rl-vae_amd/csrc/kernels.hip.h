@@ -138,6 +138,25 @@ __device__ __forceinline__ float robust_apply(float x, float c_hi, float c_lo, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// DRL_CLK_STAMPS (diagnostic builds only, tools/kernel_clock.py): workgroup 0 stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) at kernel entry and exit; their quotient is the clock the chip holds under the kernel's load
+// (MI355X_MICROARCH.md, "DVFS give-back", item 6).  In the shipped library nothing is stamped.
+#ifdef DRL_CLK_STAMPS
+__device__ unsigned long long drl_clk_dbg[4];
+struct ClkStamp {
+    bool on;
+    __device__ ClkStamp() : on(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (on) { drl_clk_dbg[0] = __builtin_amdgcn_s_memtime(); drl_clk_dbg[1] = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ ~ClkStamp() {
+        if (on) { drl_clk_dbg[2] = __builtin_amdgcn_s_memtime(); drl_clk_dbg[3] = __builtin_amdgcn_s_memrealtime(); }
+    }
+};
+#define DRL_CLK ClkStamp drl_clk_stamp_;
+#else
+#define DRL_CLK
+#endif
+
 // K2: VAE mean path + reconstruction error.  One wave = 32 windows, no LDS, no barriers.
 struct VaeArgs {
     // path = encoder hidden..., mu, decoder...  (the logvar head rides beside mu when eps != null)
@@ -751,6 +770,7 @@ __device__ __forceinline__ void rec_step(f32x16 (&pq)[REC_RING], float (&aq)[2][
 #endif
 template <int NT, bool FLAGGED>
 __global__ __launch_bounds__(256, REC_WAVES_PER_SIMD) void lstm_rec_kernel(RecArgs ra) {
+    DRL_CLK
     extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64] | flag row [NT][2][16]
     static_assert(NT % 4 == 0, "the projection ring assumes a multiple of 4 gate tiles");
     const LstmArgs& a = ra.l;
@@ -896,6 +916,7 @@ __device__ __forceinline__ void rec_step2(f32x16 (&pq)[REC_RING], float (&aq)[2]
 
 template <int NT>
 __global__ __launch_bounds__(256, 1) void lstm_rec2_kernel(RecArgs ra) {
+    DRL_CLK
     extern __shared__ __attribute__((aligned(16))) float rec_u[];     // [NT*4][NT][64] | flag row [NT][2][16]
     static_assert(NT % 4 == 0, "the projection ring assumes a multiple of 4 gate tiles");
     const LstmArgs& a = ra.l;
@@ -1047,6 +1068,7 @@ __device__ __forceinline__ void h128_pointwise(const f32x16 (&acc)[4], float (&c
 // over twice as many CUs: same arithmetic per window, half the latency.
 template <int NG>
 __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
+    DRL_CLK
     // separate objects so that alias analysis can tell group A's h from group B's
     __shared__ __attribute__((aligned(16))) float s_hA[64 * 64];   // [k-step][lane]
     __shared__ __attribute__((aligned(16))) float s_hB[64 * 64];

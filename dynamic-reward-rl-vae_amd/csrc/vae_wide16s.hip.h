@@ -27,24 +27,12 @@
 #ifdef VWS_STAMPS
 __device__ unsigned long long vws_dbg[64 * 4];
 #define VWS_STAMP(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && it < 60) vws_dbg[it * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define VWS_MARK(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0) vws_dbg[240 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VWS_MARK(i) do { if (blockIdx.x == 0 && wave == 0 && lane == 0) { vws_dbg[240 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0 || (i) == 6) vws_dbg[248 + ((i) != 0)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define VWS_MARK(i) do { } while (0)
 #define VWS_STAMP(i) do { } while (0)
 #endif
-
-// robust_apply (kernels.hip.h) on two columns at once: the same IEEE operations per element, as packed fp32
-// instructions (v_pk_add/mul/fma_f32: two floats per lane per issue; 40 -> 30 VALU instructions per slab as compiled).
-// VALU and fp32 MFMA share the SIMD's pipe, so every VALU cycle is a cycle without an MFMA; measured, though, the
-// 10 instructions of ~200 per slab pair are within the noise of the kernel's time (2.42 / 2.44 ms on C4).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 robust_apply2(f32x2 x, f32x2 c_hi, f32x2 c_lo, f32x2 i_hi, f32x2 i_lo, float clip) {
-    f32x2 t = x - c_hi;
-    t = t - c_lo;
-    const f32x2 p = t * i_lo;
-    const f32x2 r = __builtin_elementwise_fma(t, i_hi, p);
-    return f32x2{__builtin_amdgcn_fmed3f(r[0], -clip, clip), __builtin_amdgcn_fmed3f(r[1], -clip, clip)};
-}
 
 template <bool SCALED>
 __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
@@ -152,17 +140,14 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
         }
 #pragma unroll
         for (int T = 0; T < 8; ++T) av[T * 2] = *reinterpret_cast<const f32x4*>(wl + (T * 2) * 256);
+        // (two columns per call.  Packed fp32 — v_pk_add/mul/fma_f32 on the pair — was tried: 40 -> 30 instructions per
+        // slab, 2.42 -> 2.44 ms on C4; beside an MFMA stream a packed instruction costs more than the two it replaces,
+        // MI355X_MICROARCH.md "price of one filler beside MFMAs")
         auto transform = [&](int kp) __attribute__((always_inline)) {      // columns 2kp and 2kp+1 of the slab
-            const int ks = 2 * kp, h = ks >> 2, e = ks & 3;
-            if (SCALED) {
-                const f32x2 r = robust_apply2(f32x2{xv[ks], xv[ks + 1]}, f32x2{sc[0][h][e], sc[0][h][e + 1]}, f32x2{sc[1][h][e], sc[1][h][e + 1]},
-                                              f32x2{sc[2][h][e], sc[2][h][e + 1]}, f32x2{sc[3][h][e], sc[3][h][e + 1]}, clip);
-                bv[ks] = r[0];
-                bv[ks + 1] = r[1];
-            } else {
-                bv[ks] = xv[ks];
-                bv[ks + 1] = xv[ks + 1];
-            }
+#pragma unroll
+            for (int ks = 2 * kp; ks < 2 * kp + 2; ++ks)
+                bv[ks] = SCALED ? robust_apply(xv[ks], sc[0][ks >> 2][ks & 3], sc[1][ks >> 2][ks & 3], sc[2][ks >> 2][ks & 3],
+                                               sc[3][ks >> 2][ks & 3], clip) : xv[ks];
         };
 #pragma unroll
         for (int kp = 0; kp < 4; ++kp) transform(kp);
@@ -334,18 +319,9 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
 #pragma unroll
             for (int T2 = 0; T2 < 2; ++T2)
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    if (SCALED) {
-                        const f32x2 t = robust_apply2(f32x2{xv[T2 * 4 + r], xv[T2 * 4 + r + 1]}, f32x2{sc[T2][0][r], sc[T2][0][r + 1]},
-                                                      f32x2{sc[T2][1][r], sc[T2][1][r + 1]}, f32x2{sc[T2][2][r], sc[T2][2][r + 1]},
-                                                      f32x2{sc[T2][3][r], sc[T2][3][r + 1]}, clip);
-                        xt8[T2 * 4 + r] = t[0];
-                        xt8[T2 * 4 + r + 1] = t[1];
-                    } else {
-                        xt8[T2 * 4 + r] = xv[T2 * 4 + r];
-                        xt8[T2 * 4 + r + 1] = xv[T2 * 4 + r + 1];
-                    }
-                }
+                for (int r = 0; r < 4; ++r)
+                    xt8[T2 * 4 + r] = SCALED ? robust_apply(xv[T2 * 4 + r], sc[T2][0][r], sc[T2][1][r], sc[T2][2][r], sc[T2][3][r], clip)
+                                             : xv[T2 * 4 + r];
         };
         transform();
         VWS_MARK(5);
