@@ -70,6 +70,7 @@ struct VaeHost {
     size_t pack_floats = 0;               // size of the chain kernels' weight pack (what vae_kernel<.., true> copies to LDS)
     bool wide16 = false;                  // wide windows with a 97..128-wide first/last hidden layer: vae_wide16_kernel
     size_t w16_off[DRL_MAX_VAE_LAYERS], b16_off[DRL_MAX_VAE_LAYERS];   // its 16-row-tile layout, after the chain pack
+    size_t wlv16_off = 0, blv16_off = 0;  // the logvar head in the middle layers' 16-row-tile layout (has_lv && wide16)
 };
 
 struct LstmHost {
@@ -763,6 +764,11 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
             v.b16_off[p] = off;
             off += (p == last) ? nslab * 32 : up16(nout16 * 16);
         }
+        if (v.has_lv) {                      // after the path's layers: the middle layers stay contiguous
+            const size_t nin16 = (in_dims[logvar_layer] + 15) / 16, nout16 = (v.latent + 15) / 16;
+            v.wlv16_off = off; off += nout16 * nin16 * 4 * 64;
+            v.blv16_off = off; off += up16(nout16 * 16);
+        }
     }
     std::vector<float> pack(off, 0.0f);
     for (int p = 0; p < v.n_path; ++p) {
@@ -825,6 +831,27 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
                             b[(ot * 4 + qq) * 4 + r] = o < dout ? (float)(scale * B[o]) : 0.0f;
                         }
             }
+        }
+        if (v.has_lv) {                      // the logvar head, packed like a middle layer
+            const float* K = kernels[logvar_layer];
+            const float* B = biases[logvar_layer];
+            const int din = in_dims[logvar_layer], dout = v.latent;
+            const int nin16 = (din + 15) / 16, nout16 = (dout + 15) / 16;
+            float* w = pack.data() + v.wlv16_off;
+            float* b = pack.data() + v.blv16_off;
+            for (int ot = 0; ot < nout16; ++ot)
+                for (int Tin = 0; Tin < nin16; ++Tin)
+                    for (int r = 0; r < 4; ++r)
+                        for (int l = 0; l < 64; ++l) {
+                            const int in = 16 * Tin + 4 * (l >> 4) + r, out = 16 * ot + (l & 15);
+                            w[(((size_t)ot * nin16 + Tin) * 4 + r) * 64 + l] = (in < din && out < dout) ? K[(size_t)in * dout + out] : 0.0f;
+                        }
+            for (int ot = 0; ot < nout16; ++ot)
+                for (int qq = 0; qq < 4; ++qq)
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = 16 * ot + 4 * qq + r;
+                        b[(ot * 4 + qq) * 4 + r] = o < dout ? B[o] : 0.0f;
+                    }
         }
     }
     int rc = ensure(c, c->vae_w, off * sizeof(float));
@@ -1170,12 +1197,14 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         const int xr_floats = (63 * F + ((W * F + 31) & ~31) + 3) & ~3;
         size_t wide_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
         if (c->vw16_pad) wide_lds = std::min<size_t>(wide_lds + (size_t)c->vw16_pad, 160 * 1024);   // measurement knob: fewer workgroups per CU
-        const bool wide = c->vae.wide16 && !d_eps && wide_lds <= 160 * 1024;
+        const size_t s_lds = ((size_t)VWS_RING * VW16_SLAB + VWS_RING * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
+        const bool use_s = (c->vae_s == 1 && 2 * s_lds <= 160 * 1024) || (c->vae_s >= 2 && s_lds <= 160 * 1024);
+        // with eps (the reference's sampled z): only vae_wide16s_kernel carries the logvar head among the wide kernels
+        const bool wide = c->vae.wide16 && wide_lds <= 160 * 1024 && (!d_eps || (use_s && c->vae.latent <= 32));
         // the ping-pong form: two regions (+ up to 3 floats each for the 16-byte alignment of their loads) and one ring
         const int xr_pp = xr_floats + 4;
         const size_t pp_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)2 * xr_pp) * sizeof(float);
         const bool use_pp = wide && pp_wanted && pp_lds <= 160 * 1024;
-        const size_t s_lds = ((size_t)VWS_RING * VW16_SLAB + VWS_RING * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
         if (prof) prof_begin(c, 1, vst);
         if (wide) {
             if (wide_lds > c->wide_lds_set) {
@@ -1205,15 +1234,19 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 const size_t span = lastp > 1 ? c->vae.w16_off[lastp] - c->vae.w16_off[1] : 0;
                 b16.mid_floats = (span > 0 && span <= 2 * VW16_SLAB && span % 4 == 0) ? (int)span : 0;
             }
+            if (d_eps) {
+                b16.wlv16 = (const float*)c->vae_w.p + c->vae.wlv16_off;
+                b16.blv16 = (const float*)c->vae_w.p + c->vae.blv16_off;
+            }
             a.seg.tile_off = sh.d_t64;               // a tile = 64 windows of one series
             a.n_tiles = sh.tiles64;
-            if (use_pp) {
+            if (use_pp && !d_eps) {
                 // two tiles per workgroup in ping-pong, persistent: every CU a balanced share of the tiles
                 const dim3 grid(std::min(c->n_cu, (sh.tiles64 + 1) / 2));
                 if (a.rs) hipLaunchKernelGGL(vae_wide16pp_kernel<true>, grid, dim3(VWP_THREADS), pp_lds, vst, a, b16, xr_pp);
                 else hipLaunchKernelGGL(vae_wide16pp_kernel<false>, grid, dim3(VWP_THREADS), pp_lds, vst, a, b16, xr_pp);
                 c->last_vae_variant = "wide16pp";
-            } else if ((c->vae_s == 1 && 2 * s_lds <= 160 * 1024) || (c->vae_s >= 2 && s_lds <= 160 * 1024)) {
+            } else if (use_s) {
                 const dim3 grid(sh.tiles64);         // a workgroup = one tile, one workgroup per CU
                 if (a.rs) hipLaunchKernelGGL(vae_wide16s_kernel<true>, grid, dim3(256), s_lds, vst, a, b16, xr_floats);
                 else hipLaunchKernelGGL(vae_wide16s_kernel<false>, grid, dim3(256), s_lds, vst, a, b16, xr_floats);

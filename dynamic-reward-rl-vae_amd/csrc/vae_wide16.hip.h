@@ -49,6 +49,8 @@ struct Vae16Args {
     const float* b16[DRL_MAX_VAE_LAYERS];   // [ot][q 4][r 4] (layer 0, middle); last layer: natural order, slab-padded
     int mid_floats;                         // floats from w16[1] to the end of b16[n-2] (the middle layers' weights and
                                             // biases, contiguous in the pack), a multiple of 4; 0 = too large for the ring
+    const float* wlv16;                     // the logvar head in a middle layer's layout, or null (no eps: the mean path);
+    const float* blv16;                     // only vae_wide16s_kernel reads them
 };
 
 __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {

@@ -242,10 +242,16 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
         const int nin = (a.din[p] + 15) >> 4, nout = (a.dout[p] + 15) >> 4;
         const float* __restrict__ w = mid_lds ? wt + (b.w16[p] - b.w16[1]) : b.w16[p];
         const float* __restrict__ bb = mid_lds ? wt + (b.b16[p] - b.w16[1]) : b.b16[p];
-        f32x4 nxt[8];
+        // the reference's sampled z (myasp-A1.py:84, 94): the logvar head rides beside mu, from global memory (latent <= 32:
+        // two output tiles at most, host-checked)
+        const bool with_lv = b.wlv16 != nullptr && p == a.mu_idx;
+        f32x4 nxt[8], lv[2];
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot)
             nxt[ot] = ot < nout ? *reinterpret_cast<const f32x4*>(bb + (ot * 4 + q) * 4) : f32x4{};
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+            lv[ot] = (with_lv && ot < nout) ? *reinterpret_cast<const f32x4*>(b.blv16 + (ot * 4 + q) * 4) : f32x4{};
 #pragma unroll
         for (int Tin = 0; Tin < 8; ++Tin) {
             if (Tin < nin) {
@@ -256,11 +262,35 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
                         if (ot < nout)
                             nxt[ot] = mfma16x4(w[(((size_t)ot * nin + Tin) * 4 + r) * 64 + lane], cur[Tin][r], nxt[ot]);
                 }
+                if (with_lv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot)
+                            if (ot < nout)
+                                lv[ot] = mfma16x4(b.wlv16[(((size_t)ot * nin + Tin) * 4 + r) * 64 + lane], cur[Tin][r], lv[ot]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot) { cur[ot] = nxt[ot]; act4(cur[ot], a.act[p]); }
+        if (with_lv) {
+            // z = mu + exp(0.5 * clip(logvar)) * eps, vae_kernel's operations (kernels.hip.h); rows 16 ot + 4 q + r of
+            // this lane's window (a lane without a window reads the draws of its wave's last one and stores nothing)
+            const float* __restrict__ ep = a.eps + (a.seg.win_off[s] + k0 + 16 * wave + jc) * (long long)a.dout[p];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * ot + 4 * q + r;
+                    if (ot < nout && d < a.dout[p]) {
+                        float l = lv[ot][r];
+                        if (a.lv_clip > 0.0f) l = fminf(fmaxf(l, -a.lv_clip), a.lv_clip);
+                        cur[ot][r] += __builtin_amdgcn_exp2f(0.72134752044448170f * l) * ep[d];
+                    }
+                }
+        }
     }
     if (mid_lds) __syncthreads();                           // the ring is rewritten below
     VWS_MARK(4);

@@ -652,3 +652,44 @@ def test_wide_vae_kernel_variants_equal_the_one_tile_kernel(scorer, seed):
     X = orc.vae_windows_multivariate(xs, Wn, kw.get("vae_center"), kw.get("vae_scale"), 2.0 if scaled else None, lo, lo + len(xs) - Wn)
     rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], dtype=np.float64)
     np.testing.assert_allclose(got[K0:K0 + len(X)], orc.recon_error(X, rec, np.float64), rtol=RTOL)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DRLVAE_SWEEP_SEEDS", 8))))
+def test_eps_on_the_pipelined_wide_kernel_equals_the_chain_kernel(scorer, seed):
+    """The reference's sampled z (myasp-A1.py:84, 94; myasp-wadi.py:106-108) on wide windows: vae_wide16s_kernel with
+    the logvar head in its middle layers against the chain kernel (vae_kernel<4>) on the same draws — ragged batches,
+    tiles of fewer than 64 windows, series too short for a window, latent widths 3..32 (one and two 16-row tiles),
+    one or two encoder layers, logvar clip on and off — and against the fp64 oracle on the first series."""
+    rng = np.random.default_rng(9100 + seed)
+    Wn = int(rng.integers(5, 28))
+    F = int(rng.choice([17, 38, 123]))
+    hid = int(rng.choice([97, 120, 128]))
+    D = Wn * F
+    latent = int(rng.choice([3, 10, 16, 17, 32]))
+    n_enc = 1 + seed % 2
+    vae = synth_vae(rng, [D] + [hid] * n_enc + [latent, hid, D], n_enc)
+    n_seg = int(rng.integers(1, 5))
+    lens = [int(rng.integers(max(1, Wn - 2), Wn + 300)) for _ in range(n_seg)]
+    lens[int(rng.integers(0, n_seg))] = Wn + int(rng.integers(1, 500))
+    x = rng.random((sum(lens), F), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    K = int(np.maximum(np.diff(off) - Wn, 0).sum())
+    eps = rng.normal(size=(K, latent)).astype(np.float32)
+    kw = dict(vae_lag=int(seed % 3 != 0), want=("err",), eps=eps)
+    if seed % 4 != 3:
+        kw.update(vae_center=rng.uniform(0.3, 0.7, D), vae_scale=rng.uniform(0.05, 0.6, D), vae_clip=2.0)
+    scorer.set_vae(vae)
+    got = scorer.score(x, Wn, off, **kw)["err"]
+    assert scorer.vae_variant == "wide16s"
+    with scorer.knob("vae_s", 0, restore=VAE_S_DEFAULT):
+        ref = scorer.score(x, Wn, off, **kw)["err"]
+        assert scorer.vae_variant.startswith("chain")
+    np.testing.assert_allclose(got, ref, rtol=2e-6)
+    i = next(i for i, n in enumerate(lens) if n > Wn)
+    xs = x[off[i]:off[i + 1]][:Wn + 100]
+    K0 = int(np.maximum(np.diff(off)[:i] - Wn, 0).sum())
+    lo = 1 - kw["vae_lag"]
+    X = orc.vae_windows_multivariate(xs, Wn, kw.get("vae_center"), kw.get("vae_scale"), 2.0 if "vae_clip" in kw else None, lo, lo + len(xs) - Wn)
+    rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], vae["mu_layer"], vae["logvar_layer"], 10.0,
+                          eps=eps[K0:K0 + len(X)], dtype=np.float64)
+    np.testing.assert_allclose(got[K0:K0 + len(X)], orc.recon_error(X, rec, np.float64), rtol=RTOL)

@@ -13,6 +13,9 @@ sc.set_vae(wl["vae"])
 sc.set_knob("vae_s", 1)
 kw = {k: v for k, v in wl["kw"].items() if k.startswith("vae")}
 import time
+if os.environ.get("VWS_EPS"):                               # the sampled-z path: the logvar head in the middle layers
+    Kw = int(sum(max(0, b - a - wl["W"]) for a, b in zip(wl["offsets"][:-1], wl["offsets"][1:])))
+    kw["eps"] = np.random.default_rng(0).normal(size=(Kw, 10)).astype(np.float32)
 t_end = time.time() + float(os.environ.get("VWS_WARM_S", "2.5"))      # the clock the chip holds shows after seconds of load
 while time.time() < t_end:
     sc.score(wl["series"], wl["W"], wl["offsets"], want=("err",), **kw)
