@@ -272,8 +272,10 @@ const char* drl_last_lstm_variant(drl_ctx* ctx);
  * ';'-separated, e.g. "xproj_kernel<8>;lstm_rec2_kernel<8>;lstm_rec_kernel<8, true>": bench.py prices
  * roofline.traffic from exactly these kernels' rows of the committed PMC summary. */
 const char* drl_last_lstm_kernels(drl_ctx* ctx);
-/* Name of the VAE kernel the last call used: "wide16" (wide windows staged through LDS, mean path), "chain"
- * (narrow windows, explicit batches, and every call that passes eps), "chain/lds" (the same with its weights
+/* Name of the VAE kernel the last call used: "wide16s" (wide windows staged through LDS, software-pipelined;
+ * mean path and, with eps, the sampled z), "wide16" (the same layout without the pipelining: where only one
+ * "wide16s" workgroup would fit a CU; mean path only), "wide16pp" (knob vae_pp), "chain" (narrow windows,
+ * explicit batches, and calls with eps that no wide kernel takes), "chain/lds" (the same with its weights
  * copied to LDS first: calls of at most one workgroup per CU). */
 const char* drl_last_vae_variant(drl_ctx* ctx);
 /* Windows per workgroup tile of that launch for the "h128i2" kernels (16, 32 or 64: chosen from the
