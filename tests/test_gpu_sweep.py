@@ -664,6 +664,8 @@ def test_eps_on_the_pipelined_wide_kernel_equals_the_chain_kernel(scorer, seed):
     Wn = int(rng.integers(5, 28))
     F = int(rng.choice([17, 38, 123]))
     hid = int(rng.choice([97, 120, 128]))
+    if Wn * F <= 128:                                       # (narrow windows take the chain kernel whatever the hidden width)
+        F = 38
     D = Wn * F
     latent = int(rng.choice([3, 10, 16, 17, 32]))
     n_enc = 1 + seed % 2
@@ -684,7 +686,9 @@ def test_eps_on_the_pipelined_wide_kernel_equals_the_chain_kernel(scorer, seed):
     with scorer.knob("vae_s", 0, restore=VAE_S_DEFAULT):
         ref = scorer.score(x, Wn, off, **kw)["err"]
         assert scorer.vae_variant.startswith("chain")
-    np.testing.assert_allclose(got, ref, rtol=2e-6)
+    # two float32 kernels with different summation orders (16x16x4 slabs of 32 against 32x32x2 tiles): a few ulps of a
+    # mean of thousands of squares; the 600-seed soak run has one window in 150,000 at 2.2e-6
+    np.testing.assert_allclose(got, ref, rtol=5e-6)
     i = next(i for i, n in enumerate(lens) if n > Wn)
     xs = x[off[i]:off[i + 1]][:Wn + 100]
     K0 = int(np.maximum(np.diff(off)[:i] - Wn, 0).sum())
