@@ -1,21 +1,27 @@
-// K1+K2 for wide windows, one wave per SIMD, software-pipelined: vae_wide16_kernel's arithmetic (same packed weights,
-// same MFMA order per accumulator, same bits) with every memory operation of a slab issued from INSIDE the MFMA
-// stream of the slab before it.
+// K1+K2 for wide windows, software-pipelined by hand: vae_wide16_kernel's arithmetic (same packed weights, same MFMA
+// order per accumulator, same bits) with every memory operation and every input-transform instruction of a slab issued
+// from INSIDE the MFMA stream of the slab before it — one of them behind each MFMA.
 //
-// Why (round 3 measurements, tools/vw16_stamps.py and tools/pp_stamps.py).  In vae_wide16_kernel a wave spends, per
-// 32-element slab, ~900 cycles requesting the next slab and reading its 28 LDS operands, 2,048+ cycles multiplying,
-// ~600 cycles storing the staged slab and ~100 in the barrier; the second workgroup of the CU is meant to multiply
-// meanwhile, but (a) nothing keeps the two workgroups' phases apart and (b) every VALU instruction a wave issues
-// while its SIMD-mate streams fp32 MFMAs waits for the MFMA in flight (~50 cycles each), so the non-MFMA phases are
-// long: 65 % MFMA-busy.  (A workgroup barrier that alternates two tiles' phases — vae_wide16pp_kernel — removes (a)
-// and not (b): measured no faster.)  A wave's OWN loads, LDS reads and stores, however, issue in the shadow of its own
-// MFMAs for free.  So: one workgroup per CU, one wave per SIMD, and
-//   * a ring of THREE slabs: while slab i is multiplied, the second half of its A fragments and all operands of slab
-//     i+1 are read from LDS into the registers the first half has just freed (no second register set), slab i+2 is
-//     written into the ring and slab i+3 is requested from L2 — one barrier per slab, nothing in front of or behind it
-//     but MFMAs;
-//   * the input transform of a slab is computed at the top of its iteration (own-wave VALU: 4 cycles an instruction),
-//     which frees the scaler registers for the next slab's entries.
+// Why (round 3 measurements: tools/vw16_stamps.py, tools/pp_stamps.py, tools/vws_stamps.py).  In
+// vae_wide16_kernel a wave spends, per 32-element slab, ~900 ticks requesting the next slab and reading its 28 LDS
+// operands, 2,048+ multiplying, ~600 storing the staged slab and ~100 in the barrier; the second workgroup of the CU is
+// meant to multiply meanwhile, but every VALU instruction a wave issues while its SIMD-mate streams fp32 MFMAs waits for
+// the MFMA in flight (~50 ticks each), so the non-MFMA phases are long: 65 % MFMA-busy.  (A workgroup barrier that
+// alternates two tiles' phases — vae_wide16pp_kernel — keeps the phases apart and not the VALU work: measured no
+// faster.)  A wave's OWN loads, LDS reads and stores issue in the shadow of its own MFMAs, but only BETWEEN them: the
+// same instructions in a block ahead of the MFMAs cost ~17 ticks each.  So
+//   * the slab loop is 64 slots of (MFMA, one other instruction, sched_barrier).  During the first half of slab i the
+//     second-half A fragments of slab i and the inputs and scaler entries of slab i+1 are read from LDS; during the
+//     second half the first-half fragments of slab i+1, the LDS stores of slab i+2, the global loads of slab i+3 and the
+//     input transform of slab i+1 — every value lands in a register the MFMAs have just released (no second register
+//     set, no copies);
+//   * the body has no branches: past the end of a layer it reads operands nobody uses and writes the ring buffer nobody
+//     reads (with branches the compiler's waits count the longest path and the next slab's operands go through 80 v_mov);
+//   * VWS_RING = 2 slabs and TWO barriers per slab (the second one between the halves frees slab i's buffer for slab
+//     i+2), so that two workgroups still share a CU (77 KB each for WaDi): C4 2.41 ms.  VWS_RING = 3 needs one barrier
+//     per slab but fits one workgroup per CU, and then nothing covers region staging, middle layers and barriers: 2.79 ms;
+//   * with eps (the reference's sampled z) the middle layers run the logvar head beside mu.
+// The host uses this kernel where two workgroups fit a CU's LDS (knob vae_s), vae_wide16_kernel otherwise.
 //
 // Layouts, packing and the per-window arithmetic: vae_wide16.hip.h.  Results are bit-identical to that kernel (tested).
 #pragma once
@@ -37,8 +43,8 @@ __device__ unsigned long long vws_dbg[64 * 4];
 template <bool SCALED>
 __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
     extern __shared__ __attribute__((aligned(16))) float vws_smem[];
-    float* wt = vws_smem;                                   // [3][VW16_SLAB]
-    float* side = vws_smem + VWS_RING * VW16_SLAB;          // [3][VW16_SIDE]
+    float* wt = vws_smem;                                   // [VWS_RING][VW16_SLAB]
+    float* side = vws_smem + VWS_RING * VW16_SLAB;          // [VWS_RING][VW16_SIDE]
     float* xr = side + VWS_RING * VW16_SIDE;                // [xr_floats]: the workgroup's windows as one flat region
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int q = lane >> 4, col = lane & 15;
