@@ -129,8 +129,8 @@ struct drl_ctx {
     bool no_pipeline = false;     // host path: always the one-shot copy
     bool no_fused_epilogue = false;   // action / margin always by finalize_kernel
     bool rollout_dense = false;   // drl_rollout_batch: full passes only
-    int vae_s = 1;                // wide windows: the software-pipelined kernel (vae_wide16s.hip.h): 0 never, 1 when two of its
-                                  // workgroups fit a CU's LDS (measured faster then, slower alone), 2 whenever one fits
+    int vae_s = 1;                // wide windows: the software-pipelined kernel (vae_wide16s.hip.h): 1 default: wherever one of its
+                                  // workgroups fits a CU's LDS; 0: vae_wide16_kernel (tests, A/B)
     int vae_pp = 0;               // wide windows: the ping-pong kernel (two tiles per workgroup, persistent): 0 never (default:
                                   // measured slower than vae_wide16_kernel), 1 calls of more 64-window
                                   // tiles than CUs, 2 whenever its LDS fits
@@ -563,8 +563,8 @@ int drl_create(int device_id, drl_ctx** out) {
             attr(reinterpret_cast<const void*>(vae_kernel<DRL_VAE_MAX_TILES, true>), CHAIN_LDS_MAX) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<false>), 160 * 1024) &&
-            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<true>), 160 * 1024) &&
-            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<false>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<false>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>), 160 * 1024) &&
@@ -1197,8 +1197,11 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         const int xr_floats = (63 * F + ((W * F + 31) & ~31) + 3) & ~3;
         size_t wide_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
         if (c->vw16_pad) wide_lds = std::min<size_t>(wide_lds + (size_t)c->vw16_pad, 160 * 1024);   // measurement knob: fewer workgroups per CU
-        const size_t s_lds = ((size_t)VWS_RING * VW16_SLAB + VWS_RING * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
-        const bool use_s = (c->vae_s == 1 && 2 * s_lds <= 160 * 1024) || (c->vae_s >= 2 && s_lds <= 160 * 1024);
+        // vae_wide16s_kernel wherever one of its workgroups fits: two per CU for the benchmark shapes (C4 2.41 ms against
+        // vae_wide16_kernel's 2.66), one per CU for wider inputs (F = 140: 2.30 ms against 2.78; a ring of three slabs
+        // with one barrier per slab measured the same 2.31 there, so it is not instantiated)
+        const size_t s_lds = ((size_t)2 * VW16_SLAB + 2 * VW16_SIDE + (size_t)xr_floats) * sizeof(float);
+        const bool use_s = c->vae_s != 0 && s_lds <= 160 * 1024;
         // with eps (the reference's sampled z): only vae_wide16s_kernel carries the logvar head among the wide kernels
         const bool wide = c->vae.wide16 && wide_lds <= 160 * 1024 && (!d_eps || (use_s && c->vae.latent <= 32));
         // the ping-pong form: two regions (+ up to 3 floats each for the 16-byte alignment of their loads) and one ring
@@ -1212,9 +1215,9 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<true>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<false>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
@@ -1248,8 +1251,8 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 c->last_vae_variant = "wide16pp";
             } else if (use_s) {
                 const dim3 grid(sh.tiles64);         // a workgroup = one tile, one workgroup per CU
-                if (a.rs) hipLaunchKernelGGL(vae_wide16s_kernel<true>, grid, dim3(256), s_lds, vst, a, b16, xr_floats);
-                else hipLaunchKernelGGL(vae_wide16s_kernel<false>, grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                if (a.rs) hipLaunchKernelGGL((vae_wide16s_kernel<true, 2>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                else hipLaunchKernelGGL((vae_wide16s_kernel<false, 2>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
                 c->last_vae_variant = "wide16s";
             } else {
                 const dim3 grid(sh.tiles64);         // a workgroup = one tile

@@ -17,18 +17,17 @@
 //     set, no copies);
 //   * the body has no branches: past the end of a layer it reads operands nobody uses and writes the ring buffer nobody
 //     reads (with branches the compiler's waits count the longest path and the next slab's operands go through 80 v_mov);
-//   * VWS_RING = 2 slabs and TWO barriers per slab (the second one between the halves frees slab i's buffer for slab
-//     i+2), so that two workgroups still share a CU (77 KB each for WaDi): C4 2.41 ms.  VWS_RING = 3 needs one barrier
-//     per slab but fits one workgroup per CU, and then nothing covers region staging, middle layers and barriers: 2.79 ms;
+//   * a ring of 2 slabs and TWO barriers per slab (the second one between the halves frees slab i's buffer for slab
+//     i+2), so that two workgroups still share a CU (77 KB each for WaDi): C4 2.41 ms.  A ring of 3 needs one barrier per
+//     slab but fits one workgroup per CU, and then nothing covers region staging, middle layers and barriers: 2.79 ms.
+//     Where the region leaves room for one workgroup anyway (more than ~131 sensors at W = 25) the two rings measure
+//     the same (F = 140, 131,072 windows: 2.30 / 2.31 ms, vae_wide16_kernel 2.78), so only the ring of 2 is instantiated;
 //   * with eps (the reference's sampled z) the middle layers run the logvar head beside mu.
-// The host uses this kernel where two workgroups fit a CU's LDS (knob vae_s), vae_wide16_kernel otherwise.
+// The host uses this kernel wherever one of its workgroups fits a CU's LDS (knob vae_s = 0: vae_wide16_kernel).
 //
 // Layouts, packing and the per-window arithmetic: vae_wide16.hip.h.  Results are bit-identical to that kernel (tested).
 #pragma once
 
-#ifndef VWS_RING
-#define VWS_RING 2
-#endif
 
 #ifdef VWS_STAMPS
 __device__ unsigned long long vws_dbg[64 * 4];
@@ -40,8 +39,10 @@ __device__ unsigned long long vws_dbg[64 * 4];
 #define VWS_STAMP(i) do { } while (0)
 #endif
 
-template <bool SCALED>
+// VWS_RING: slabs in the weight ring.  2: two barriers per slab (shipped); 3: one barrier per slab (A/B builds).
+template <bool SCALED, int VWS_RING>
 __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
+    static_assert(VWS_RING == 2 || VWS_RING == 3, "ring of two or three slabs");
     extern __shared__ __attribute__((aligned(16))) float vws_smem[];
     float* wt = vws_smem;                                   // [VWS_RING][VW16_SLAB]
     float* side = vws_smem + VWS_RING * VW16_SLAB;          // [VWS_RING][VW16_SIDE]

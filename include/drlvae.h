@@ -273,8 +273,8 @@ const char* drl_last_lstm_variant(drl_ctx* ctx);
  * roofline.traffic from exactly these kernels' rows of the committed PMC summary. */
 const char* drl_last_lstm_kernels(drl_ctx* ctx);
 /* Name of the VAE kernel the last call used: "wide16s" (wide windows staged through LDS, software-pipelined;
- * mean path and, with eps, the sampled z), "wide16" (the same layout without the pipelining: where only one
- * "wide16s" workgroup would fit a CU; mean path only), "wide16pp" (knob vae_pp), "chain" (narrow windows,
+ * mean path and, with eps, the sampled z), "wide16" (the same layout without the pipelining: knob vae_s = 0;
+ * mean path only), "wide16pp" (knob vae_pp), "chain" (narrow windows,
  * explicit batches, and calls with eps that no wide kernel takes), "chain/lds" (the same with its weights
  * copied to LDS first: calls of at most one workgroup per CU). */
 const char* drl_last_vae_variant(drl_ctx* ctx);
@@ -301,8 +301,8 @@ int drl_last_call_overlapped(drl_ctx* ctx);
  *   pipe_min bytes, pipe_chunk samples, no_pipeline 0|1    the pipelined host path of drl_score_batch
  *   no_fused_epilogue 0|1  action / margin always by finalize_kernel
  *   rollout_dense 0|1      drl_rollout_batch: full passes only
- *   vae_s 0|1|2            wide windows: the software-pipelined kernel (vae_wide16s_kernel) never | where two of its
- *                          workgroups fit a CU's LDS (default) | wherever one fits; else vae_wide16_kernel (same bits)
+ *   vae_s 0|1              wide windows: 1 default, the software-pipelined kernel (vae_wide16s_kernel) wherever one of its
+ *                          workgroups fits a CU's LDS; 0: vae_wide16_kernel instead (same bits; tests, A/B)
  *   vae_pp 0|1|2           wide windows: the ping-pong kernel (vae_wide16pp_kernel; same bits, measured slower):
  *                          never (default) | from a full round of tile pairs | always
  * Unknown names: DRL_ERR_ARG. */

@@ -638,7 +638,7 @@ def test_wide_vae_kernel_variants_equal_the_one_tile_kernel(scorer, seed):
         got = scorer.score(x, Wn, off, **kw)["err"]
         assert scorer.vae_variant == "wide16pp"
     assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (Wn, F, hid, lens, kw.keys())
-    with scorer.knob("vae_s", 2, restore=VAE_S_DEFAULT):
+    with scorer.knob("vae_s", 1, restore=VAE_S_DEFAULT):
         got_s = scorer.score(x, Wn, off, **kw)["err"]
         assert scorer.vae_variant == "wide16s"
     assert np.array_equal(ref.view(np.uint32), got_s.view(np.uint32)), ("wide16s", Wn, F, hid, lens, kw.keys())
@@ -700,9 +700,10 @@ def test_eps_on_the_pipelined_wide_kernel_equals_the_chain_kernel(scorer, seed):
 
 
 def test_wide_kernels_when_only_one_workgroup_fits_a_cu(scorer):
-    """F = 140 sensors at W = 25: the flat region of 64 windows is 49 KB, two software-pipelined workgroups no longer
-    fit a CU's LDS, so the default is vae_wide16_kernel; vae_s = 2 runs vae_wide16s_kernel alone on its CU.  Same bits,
-    and the oracle's error; with eps the call takes the chain kernel unless vae_s = 2."""
+    """F = 140 sensors at W = 25: the flat region of 64 windows is 49 KB and two software-pipelined workgroups no longer
+    fit a CU's LDS; vae_wide16s_kernel then runs alone on its CU (still 17 % faster than vae_wide16_kernel there:
+    tools/wide_f140.py).  Same bits as vae_wide16_kernel (vae_s = 0), the oracle's error, and the same draws with eps
+    through it and through the chain kernel."""
     rng = np.random.default_rng(77)
     Wn, F, hid, latent = 25, 140, 128, 10
     D = Wn * F
@@ -712,19 +713,19 @@ def test_wide_kernels_when_only_one_workgroup_fits_a_cu(scorer):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     kw = dict(vae_lag=0, want=("err",), vae_center=rng.uniform(0.3, 0.7, D), vae_scale=rng.uniform(0.05, 0.6, D), vae_clip=2.0)
     scorer.set_vae(vae)
-    ref = scorer.score(x, Wn, off, **kw)["err"]
-    assert scorer.vae_variant == "wide16"
-    with scorer.knob("vae_s", 2, restore=VAE_S_DEFAULT):
-        got = scorer.score(x, Wn, off, **kw)["err"]
-        assert scorer.vae_variant == "wide16s"
-    assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    got = scorer.score(x, Wn, off, **kw)["err"]
+    assert scorer.vae_variant == "wide16s"
+    with scorer.knob("vae_s", 0, restore=VAE_S_DEFAULT):
+        other = scorer.score(x, Wn, off, **kw)["err"]
+        assert scorer.vae_variant == "wide16"
+    assert np.array_equal(other.view(np.uint32), got.view(np.uint32))
     X = orc.vae_windows_multivariate(x[:lens[0]], Wn, kw["vae_center"], kw["vae_scale"], 2.0, 1, 1 + lens[0] - Wn)
     rec = orc.vae_forward(X, vae["kernels"], vae["biases"], vae["acts"], 1, 2, dtype=np.float64)
     np.testing.assert_allclose(got[:len(X)], orc.recon_error(X, rec, np.float64), rtol=RTOL)
-    eps = rng.normal(size=(len(ref), latent)).astype(np.float32)
+    eps = rng.normal(size=(len(got), latent)).astype(np.float32)
     e1 = scorer.score(x, Wn, off, eps=eps, **kw)["err"]
-    assert scorer.vae_variant.startswith("chain")
-    with scorer.knob("vae_s", 2, restore=VAE_S_DEFAULT):
-        e2 = scorer.score(x, Wn, off, eps=eps, **kw)["err"]
-        assert scorer.vae_variant == "wide16s"
-    np.testing.assert_allclose(e2, e1, rtol=2e-6)
+    assert scorer.vae_variant == "wide16s"
+    with scorer.knob("vae_s", 0, restore=VAE_S_DEFAULT):
+        e0 = scorer.score(x, Wn, off, eps=eps, **kw)["err"]
+        assert scorer.vae_variant.startswith("chain")
+    np.testing.assert_allclose(e1, e0, rtol=5e-6)
