@@ -68,7 +68,7 @@ struct VaeHost {
     int D = 0;                            // input width
     bool narrow = false;                  // every hidden width <= 64: vae_kernel<2>
     size_t pack_floats = 0;               // size of the chain kernels' weight pack (what vae_kernel<.., true> copies to LDS)
-    bool wide16 = false;                  // wide windows with a 97..128-wide first/last hidden layer: vae_wide16_kernel
+    bool wide16 = false;                  // wide windows (D > 128) with first/last hidden layers of at most 128 units: the vae_wide16* kernels
     size_t w16_off[DRL_MAX_VAE_LAYERS], b16_off[DRL_MAX_VAE_LAYERS];   // its 16-row-tile layout, after the chain pack
     size_t wlv16_off = 0, blv16_off = 0;  // the logvar head in the middle layers' 16-row-tile layout (has_lv && wide16)
 };
@@ -563,8 +563,10 @@ int drl_create(int device_id, drl_ctx** out) {
             attr(reinterpret_cast<const void*>(vae_kernel<DRL_VAE_MAX_TILES, true>), CHAIN_LDS_MAX) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16_kernel<false>), 160 * 1024) &&
-            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2>), 160 * 1024) &&
-            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2, 8>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2, 8>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2, 4>), 160 * 1024) &&
+            attr(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2, 4>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(vae_wide16pp_kernel<false>), 160 * 1024) &&
             attr(reinterpret_cast<const void*>(lstm_rec_kernel<8, true>), 160 * 1024) &&
@@ -753,7 +755,9 @@ int drl_set_vae(drl_ctx* c, int n_layers, const int32_t* in_dims, const int32_t*
     v.pack_floats = off;
     // wide windows (vae_wide16_kernel): a second copy of the path's weights in 16-row-tile order
     const int last = v.n_path - 1;
-    v.wide16 = v.D > 128 && v.dout[0] > 96 && v.dout[0] <= 128 && v.din[last] > 96 && v.din[last] <= 128;
+    // (any hidden width up to 128: the 16-row-tile layout is zero-padded to 8 tiles.  Until round 3 widths up to 96 took the
+    // chain kernel, which measures 4.2 ms at 64 and 5.2 ms at 96 hidden units where this path takes 2.4 ms at 128.)
+    v.wide16 = v.D > 128 && v.dout[0] <= 128 && v.din[last] <= 128;
     for (int p = 1; p < last && v.wide16; ++p) v.wide16 = v.din[p] <= 128 && v.dout[p] <= 128;
     if (v.wide16) {
         const size_t nslab = (v.D + 31) / 32;
@@ -1215,9 +1219,13 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2, 8>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2>),
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2, 8>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<true, 2, 4>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+                HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16s_kernel<false, 2, 4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
                 HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(vae_wide16pp_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
@@ -1251,8 +1259,15 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 c->last_vae_variant = "wide16pp";
             } else if (use_s) {
                 const dim3 grid(sh.tiles64);         // a workgroup = one tile, one workgroup per CU
-                if (a.rs) hipLaunchKernelGGL((vae_wide16s_kernel<true, 2>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
-                else hipLaunchKernelGGL((vae_wide16s_kernel<false, 2>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                // hidden layers of at most 64 units beside the windows: the instantiation that skips the zero row tiles
+                const bool nt4 = c->vae.dout[0] <= 64 && c->vae.din[c->vae.n_path - 1] <= 64;
+                if (nt4) {
+                    if (a.rs) hipLaunchKernelGGL((vae_wide16s_kernel<true, 2, 4>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                    else hipLaunchKernelGGL((vae_wide16s_kernel<false, 2, 4>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                } else {
+                    if (a.rs) hipLaunchKernelGGL((vae_wide16s_kernel<true, 2, 8>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                    else hipLaunchKernelGGL((vae_wide16s_kernel<false, 2, 8>), grid, dim3(256), s_lds, vst, a, b16, xr_floats);
+                }
                 c->last_vae_variant = "wide16s";
             } else {
                 const dim3 grid(sh.tiles64);         // a workgroup = one tile

@@ -40,9 +40,13 @@ __device__ unsigned long long vws_dbg[64 * 4];
 #endif
 
 // VWS_RING: slabs in the weight ring.  2: two barriers per slab (shipped); 3: one barrier per slab (A/B builds).
-template <bool SCALED, int VWS_RING>
+// NT: 16-row tiles of the first and last hidden layer that can be non-zero (8: widths up to 128; 4: up to 64).  The packed
+// layout is that of 8 tiles either way (vae_wide16.hip.h, zero-padded); the MFMAs and fragment reads of the tiles beyond
+// NT are simply not issued — their products are exact zeros.
+template <bool SCALED, int VWS_RING, int NT>
 __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
     static_assert(VWS_RING == 2 || VWS_RING == 3, "ring of two or three slabs");
+    static_assert(NT == 4 || NT == 8, "four or eight row tiles");
     extern __shared__ __attribute__((aligned(16))) float vws_smem[];
     float* wt = vws_smem;                                   // [VWS_RING][VW16_SLAB]
     float* side = vws_smem + VWS_RING * VW16_SLAB;          // [VWS_RING][VW16_SIDE]
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             }
         }
 #pragma unroll
-        for (int T = 0; T < 8; ++T) av[T * 2] = *reinterpret_cast<const f32x4*>(wl + (T * 2) * 256);
+        for (int T = 0; T < NT; ++T) av[T * 2] = *reinterpret_cast<const f32x4*>(wl + (T * 2) * 256);
         // (two columns per call.  Packed fp32 — v_pk_add/mul/fma_f32 on the pair — was tried: 40 -> 30 instructions per
         // slab, 2.42 -> 2.44 ms on C4; beside an MFMA stream a packed instruction costs more than the two it replaces,
         // MI355X_MICROARCH.md "price of one filler beside MFMAs")
@@ -187,9 +191,9 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int T = 0; T < 8; ++T) {
-                    cur[T] = mfma16x4(av[T * 2][ks], bv[ks], cur[T]);
+                    if (T < NT) cur[T] = mfma16x4(av[T * 2][ks], bv[ks], cur[T]);
                     const int n = ks * 8 + T;
-                    if (n < 8) av[n * 2 + 1] = *reinterpret_cast<const f32x4*>(wb + (n * 2 + 1) * 256);
+                    if (n < 8) { if (n < NT) av[n * 2 + 1] = *reinterpret_cast<const f32x4*>(wb + (n * 2 + 1) * 256); }
                     else if (n < 16) xv[n - 8] = xt[4 * (n - 8)];
                     else if (n < 24) { if (SCALED) sc[(n - 16) >> 1][(n - 16) & 1] = *reinterpret_cast<const f32x4*>(sb + ((n - 16) >> 1) * 32 + ((n - 16) & 1) * 4); }
                     __builtin_amdgcn_sched_barrier(0);
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             for (int ks = 4; ks < 8; ++ks)
 #pragma unroll
                 for (int T = 0; T < 8; ++T) {
-                    cur[T] = mfma16x4(av[T * 2 + 1][ks & 3], bv[ks], cur[T]);
+                    if (T < NT) cur[T] = mfma16x4(av[T * 2 + 1][ks & 3], bv[ks], cur[T]);
                     const int n = (ks - 4) * 8 + T;
-                    if (n < 8) av[n * 2] = *reinterpret_cast<const f32x4*>(wn + (n * 2) * 256);
+                    if (n < 8) { if (n < NT) av[n * 2] = *reinterpret_cast<const f32x4*>(wn + (n * 2) * 256); }
                     else if (n < 12) *reinterpret_cast<f32x4*>(stp + (n - 8) * 1024) = stg[n - 8];
                     else if (n == 12) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
                     else if (n == 13) { vw16_stage_load(stg, wp, voff); if (side_thr) side_next = sp[0]; }
@@ -386,13 +390,13 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
                 for (int r = 0; r < 4; ++r) {
                     const int n = Tin * 4 + r;
                     acc0 = mfma16x4(av[Tin][r], cur[Tin][r], acc0);
-                    if (n < 4) av[4 + n] = *reinterpret_cast<const f32x4*>(wb + (4 + n) * 256);
+                    if (n < 4) { if (4 + n < NT) av[4 + n] = *reinterpret_cast<const f32x4*>(wb + (4 + n) * 256); }
                     else if (n == 4) accn0 = *reinterpret_cast<const f32x4*>(sb + 128);
                     else if (n < 9) { if (SCALED) sc[0][n - 5] = *reinterpret_cast<const f32x4*>(sb + (n - 5) * 32); }
                     else if (n < 13) xv[n - 9] = xt[n - 9];
                     __builtin_amdgcn_sched_barrier(0);
                     acc1 = mfma16x4(av[8 + Tin][r], cur[Tin][r], acc1);
-                    if (n < 4) av[12 + n] = *reinterpret_cast<const f32x4*>(wb + (12 + n) * 256);
+                    if (n < 4) { if (4 + n < NT) av[12 + n] = *reinterpret_cast<const f32x4*>(wb + (12 + n) * 256); }
                     else if (n == 4) accn1 = *reinterpret_cast<const f32x4*>(sb + 128 + 16);
                     else if (n < 9) { if (SCALED) sc[1][n - 5] = *reinterpret_cast<const f32x4*>(sb + (n - 5) * 32 + 16); }
                     else if (n < 13) xv[4 + n - 9] = xt[16 + n - 9];
@@ -407,12 +411,12 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = (Tin - 4) * 4 + r;
-                    acc0 = mfma16x4(av[Tin][r], cur[Tin][r], acc0);
+                    if (Tin < NT) acc0 = mfma16x4(av[Tin][r], cur[Tin][r], acc0);
                     if (n < 4) av[n] = *reinterpret_cast<const f32x4*>(wn + n * 256);
                     else if (n < 8) *reinterpret_cast<f32x4*>(stp + (n - 4) * 1024) = stg[n - 4];
                     else if (n == 8) { vw16_stage_load(stg, wp, voff); }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc1 = mfma16x4(av[8 + Tin][r], cur[Tin][r], acc1);
+                    if (Tin < NT) acc1 = mfma16x4(av[8 + Tin][r], cur[Tin][r], acc1);
                     if (n < 4) av[8 + n] = *reinterpret_cast<const f32x4*>(wn + (8 + n) * 256);
                     else if (n == 4) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
                     else if (n == 8) { if (side_thr) side_next = sp[0]; }
