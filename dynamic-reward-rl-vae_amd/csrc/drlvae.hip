@@ -129,6 +129,7 @@ struct drl_ctx {
     bool no_pipeline = false;     // host path: always the one-shot copy
     bool no_fused_epilogue = false;   // action / margin always by finalize_kernel
     bool rollout_dense = false;   // drl_rollout_batch: full passes only
+    bool h128_split = true;       // lstm_h128p: a last round that is at most half full runs as 32-window tiles (tests: off)
     int vae_s = 1;                // wide windows: the software-pipelined kernel (vae_wide16s.hip.h): 1 default: wherever one of its
                                   // workgroups fits a CU's LDS; 0: vae_wide16_kernel (tests, A/B)
     int vae_pp = 0;               // wide windows: the ping-pong kernel (two tiles per workgroup, persistent): 0 never (default:
@@ -583,7 +584,7 @@ int drl_create(int device_id, drl_ctx** out) {
     }
     // the environment is read here and nowhere else
     for (const char* name : {"force_generic", "overlap", "rec2", "rollout", "gemv_rounds", "vw16_pad", "rec_lds_pad", "pbuf_max",
-                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense", "vae_pp", "vae_s"}) {
+                             "pipe_min", "pipe_chunk", "no_pipeline", "no_fused_epilogue", "rollout_dense", "vae_pp", "vae_s", "h128_split"}) {
         std::string var = "DRLVAE_";
         for (const char* p = name; *p; ++p) var += (char)toupper((unsigned char)*p);
         if (const char* e = getenv(var.c_str())) (void)drl_set_knob(c, name, atoll(e));
@@ -664,6 +665,7 @@ int drl_set_knob(drl_ctx* c, const char* name, long long v) {
     else if (n == "no_fused_epilogue") c->no_fused_epilogue = v != 0;
     else if (n == "rollout_dense") c->rollout_dense = v != 0;
     else if (n == "vae_s") c->vae_s = (int)v;
+    else if (n == "h128_split") c->h128_split = v != 0;
     else if (n == "vae_pp") c->vae_pp = (int)std::min<long long>(2, std::max<long long>(0, v));
     else return fail(c, DRL_ERR_ARG, "drl_set_knob: unknown knob '%s'", name);
     return DRL_OK;
@@ -1395,11 +1397,36 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 hipLaunchKernelGGL(lstm_h128p_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, ra);
                 ran("lstm_h128p_kernel<1>");
             } else {
-                a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+                // Persistent workgroups, G per candidate, walk 64-window tiles.  When the last round is at most half full
+                // its tiles run as 32-window tiles instead (lstm_h128p_kernel<1>: half as long), one per workgroup:
+                // C3 with 128 hidden units is 445 tiles on 128 workgroups = 3.48 rounds, 3.5 this way instead of 4.
+                // A 64-window tile j of a series is its 32-window tiles 2j and 2j+1, so the tiles from n_main on are
+                // the 32-window tiles from t0 on.
+                const int G = std::max(1, c->n_cu / a.S);
+                const int rem = sh.tiles64 % G;
+                int n_main = sh.tiles64, t0 = sh.tiles32;
+                if (c->h128_split && sh.tiles64 > G && rem != 0 && 2 * rem <= G) {
+                    n_main = sh.tiles64 - rem;
+                    long long a64 = 0, a32 = 0;
+                    for (int i = 0; i < n_seg; ++i) {
+                        const long long K = std::max<long long>(0, seg_offsets[i + 1] - seg_offsets[i] - W);
+                        const long long s64 = (K + 63) / 64;
+                        if (n_main < a64 + s64) { t0 = (int)(a32 + 2 * (n_main - a64)); break; }
+                        a64 += s64; a32 += (K + 31) / 32;
+                    }
+                }
+                a.seg.tile_off = sh.d_t64; a.n_tiles = n_main;
                 ra.l = a;
-                const unsigned gx = std::min<unsigned>(sh.tiles64, std::max(1, c->n_cu / a.S));
+                const unsigned gx = std::min<unsigned>(n_main, G);
                 hipLaunchKernelGGL(lstm_h128p_kernel<2>, dim3(gx, a.S), dim3(256), 0, c->stream, ra);
                 ran("lstm_h128p_kernel<2>");
+                if (n_main < sh.tiles64) {
+                    a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32;
+                    ra.l = a; ra.tile0 = t0;
+                    hipLaunchKernelGGL(lstm_h128p_kernel<1>, dim3(std::min<unsigned>(sh.tiles32 - t0, G), a.S), dim3(256), 0, c->stream, ra);
+                    ran("lstm_h128p_kernel<1>");
+                    a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+                }
             }
             c->last_variant = "xproj+h128";
         } else if (c->lstm.NT == 8 && use_proj) {

@@ -681,7 +681,7 @@ struct RecArgs {
     const float* flagw;      // packed [NT][2][16]: the flag row of Wx in accumulator order
     int win_rows;            // projected rows between consecutive windows: 1 (sliding windows of a series) or
                              // W (explicit estimator.predict states: every state brings its own W rows)
-    int tile0 = 0;           // lstm_rec_kernel / lstm_rec2_kernel: this launch covers tiles [tile0, l.n_tiles)
+    int tile0 = 0;           // lstm_rec_kernel / lstm_rec2_kernel / lstm_h128p_kernel: this launch covers tiles [tile0, l.n_tiles)
 };
 
 // 4 waves per workgroup (one per SIMD), each an independent 32-window x 1-candidate recurrence:
@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(256, 1) void lstm_h128p_kernel(RecArgs ra) {
     const int wu = __builtin_amdgcn_readfirstlane(w);      // wave-uniform: the chunk bases stay scalar
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int tile = ra.tile0 + blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {     // this launch: tiles [tile0, n_tiles)
         const SegHit sg = seg_lookup(s_seg, a.seg, tile);
         const long long k0 = (long long)(tile - sg.tile0) * (32 * NG);
         const int count = (int)(sg.Ks - k0 < 32 * NG ? sg.Ks - k0 : 32 * NG);

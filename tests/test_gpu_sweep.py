@@ -729,3 +729,28 @@ def test_wide_kernels_when_only_one_workgroup_fits_a_cu(scorer):
         e0 = scorer.score(x, Wn, off, eps=eps, **kw)["err"]
         assert scorer.vae_variant.startswith("chain")
     np.testing.assert_allclose(e1, e0, rtol=5e-6)
+
+
+@pytest.mark.parametrize("mode,S", [("both", 2), ("zeros", 1)])
+def test_h128p_last_round_as_half_tiles_is_bit_identical(scorer, mode, S):
+    """Multivariate streams with more than 64 hidden units (lstm_h128p_kernel): when the last round of 64-window tiles
+    is at most half full the library runs it as 32-window tiles in a second launch (knob h128_split).  Q, action and
+    margin must be the same bits as the one-launch form (which the other tests hold to the oracle) — on a ragged batch
+    whose split point falls inside a series, with series too short for a window in front of and behind it."""
+    rng = np.random.default_rng(4400 + S)
+    Wn, F, H = 12, 3, 96
+    G = 256 // S                                            # persistent workgroups per candidate state on an MI355X
+    lens = [Wn - 1, Wn + 64 * 40 + 7, Wn + 3, 0, Wn + 64 * (G - 45) + 33, Wn + 64 * 30 + 20, 5]     # G + 29 tiles of 64
+    x = rng.random((sum(lens), F), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    scorer.set_lstm(synth_lstm(rng, F + 1, H))
+    kw = dict(vae_lag=0, flag_mode=mode, want=("q", "action", "margin"))
+    if S == 2:
+        kw["action_rule"] = "wadi"
+    got = scorer.score(x, Wn, off, **kw)
+    assert scorer.lstm_kernels == ["xproj_kernel<8>", "lstm_h128p_kernel<2>", "lstm_h128p_kernel<1>"], scorer.lstm_kernels
+    with scorer.knob("h128_split", 0, restore=1):
+        ref = scorer.score(x, Wn, off, **kw)
+        assert scorer.lstm_kernels == ["xproj_kernel<8>", "lstm_h128p_kernel<2>"], scorer.lstm_kernels
+    for k in ("q", "action", "margin"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
