@@ -1333,6 +1333,24 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
         c->last_tile = 0;
         c->last_kernels.clear();
         auto ran = [&](const char* name) { if (!c->last_kernels.empty()) c->last_kernels += ';'; c->last_kernels += name; };
+        // Persistent kernels whose G workgroups (per candidate state) walk 64-window tiles: when the last round is at most
+        // half full, its tiles run as 32-window tiles in a second launch of the <1> instantiation — half as long, one tile
+        // per workgroup (C3 with 128 hidden units: 445 tiles on 128 workgroups = 3.48 rounds, 3.5 this way instead of 4).
+        // A 64-window tile j of a series is its 32-window tiles 2j and 2j+1, so the 64-window tiles from n_main on are the
+        // 32-window tiles from t0 on.  n_main = tiles64 when the call is not split.
+        auto half_tile_split = [&](int G, int& n_main, int& t0) {
+            n_main = sh.tiles64; t0 = sh.tiles32;
+            const int rem = sh.tiles64 % G;
+            if (!c->h128_split || sh.tiles64 <= G || rem == 0 || 2 * rem > G) return;
+            n_main = sh.tiles64 - rem;
+            long long a64 = 0, a32 = 0;
+            for (int i = 0; i < n_seg; ++i) {
+                const long long K = std::max<long long>(0, seg_offsets[i + 1] - seg_offsets[i] - W);
+                const long long s64 = (K + 63) / 64;
+                if (n_main < a64 + s64) { t0 = (int)(a32 + 2 * (n_main - a64)); break; }
+                a64 += s64; a32 += (K + 31) / 32;
+            }
+        };
         if (prof) prof_begin(c, 0, c->stream, want_vae && !overlap);   // serial: the VAE kernel's end event is the start
         if (fast && c->tl_n > 0 && c->lstm.has16) {
             // a sparse pass of the rollout's fixed point: only the listed 16-window tiles
@@ -1373,10 +1391,19 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
             ran("lstm_h128i2_kernel<1>");
             c->last_variant = "h128i2"; c->last_tile = 32;
         } else if (fast) {
-            a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
-            // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once)
-            hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(sh.tiles64, c->n_cu), a.S), dim3(256), 0, c->stream, a);
+            // persistent: one workgroup per CU walks the tiles (the recurrent weights are loaded once).  A last round
+            // that is at most half full runs as 32-window tiles in a second launch (see half_tile_split)
+            int n_main, t0;
+            half_tile_split(c->n_cu, n_main, t0);
+            a.seg.tile_off = sh.d_t64; a.n_tiles = n_main;
+            hipLaunchKernelGGL(lstm_h128i2_kernel<2>, dim3(std::min<unsigned>(n_main, c->n_cu), a.S), dim3(256), 0, c->stream, a);
             ran("lstm_h128i2_kernel<2>");
+            if (n_main < sh.tiles64) {
+                a.seg.tile_off = sh.d_t32; a.n_tiles = sh.tiles32; a.tile0 = t0;
+                hipLaunchKernelGGL(lstm_h128i2_kernel<1>, dim3(std::min<unsigned>(sh.tiles32 - t0, c->n_cu), a.S), dim3(256), 0, c->stream, a);
+                ran("lstm_h128i2_kernel<1>");
+                a.tile0 = 0; a.seg.tile_off = sh.d_t64; a.n_tiles = sh.tiles64;
+            }
             c->last_variant = "h128i2"; c->last_tile = 64;
         } else if (c->lstm.NT == 16 && use_proj) {
             // multivariate H = 128: project every sample once (16 gate tiles), then the register-stationary
@@ -1397,24 +1424,9 @@ int score_impl(drl_ctx* c, const float* d_series, const int64_t* seg_offsets, in
                 hipLaunchKernelGGL(lstm_h128p_kernel<1>, dim3(sh.tiles32, a.S), dim3(256), 0, c->stream, ra);
                 ran("lstm_h128p_kernel<1>");
             } else {
-                // Persistent workgroups, G per candidate, walk 64-window tiles.  When the last round is at most half full
-                // its tiles run as 32-window tiles instead (lstm_h128p_kernel<1>: half as long), one per workgroup:
-                // C3 with 128 hidden units is 445 tiles on 128 workgroups = 3.48 rounds, 3.5 this way instead of 4.
-                // A 64-window tile j of a series is its 32-window tiles 2j and 2j+1, so the tiles from n_main on are
-                // the 32-window tiles from t0 on.
                 const int G = std::max(1, c->n_cu / a.S);
-                const int rem = sh.tiles64 % G;
-                int n_main = sh.tiles64, t0 = sh.tiles32;
-                if (c->h128_split && sh.tiles64 > G && rem != 0 && 2 * rem <= G) {
-                    n_main = sh.tiles64 - rem;
-                    long long a64 = 0, a32 = 0;
-                    for (int i = 0; i < n_seg; ++i) {
-                        const long long K = std::max<long long>(0, seg_offsets[i + 1] - seg_offsets[i] - W);
-                        const long long s64 = (K + 63) / 64;
-                        if (n_main < a64 + s64) { t0 = (int)(a32 + 2 * (n_main - a64)); break; }
-                        a64 += s64; a32 += (K + 31) / 32;
-                    }
-                }
+                int n_main, t0;
+                half_tile_split(G, n_main, t0);
                 a.seg.tile_off = sh.d_t64; a.n_tiles = n_main;
                 ra.l = a;
                 const unsigned gx = std::min<unsigned>(n_main, G);

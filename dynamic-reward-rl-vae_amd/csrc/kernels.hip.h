@@ -473,6 +473,7 @@ struct LstmArgs {
     int S;                  // candidate states per window (gridDim.y)
     float* q;               // [K_total, S, A]
     const int* tile_list;   // null, or the n_tiles tile indices to work on (the sparse passes of drl_rollout_batch)
+    int tile0;              // lstm_h128i2_kernel: this launch covers tiles [tile0, n_tiles) (0 unless the call is split)
     // argmax epilogue (reference myasp-A1.py:227 np.argmax; :255 AL margin; myasp-wadi.py:328 WaDi rule): when the
     // kernel that computes a window's Q holds all the values the rule needs, it writes action and margin itself
     // (host: fused_epilogue); otherwise finalize_kernel does, from q.  Either may be null.
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(256, 1) void lstm_h128i2_kernel(LstmArgs a) {
     const float fb = a.forget_bias;
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    for (int tile = a.tile0 + blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
 #if H128_ABL == 3
         break;                                  // timing-only: the prologue alone
 #endif

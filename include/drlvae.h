@@ -303,8 +303,8 @@ int drl_last_call_overlapped(drl_ctx* ctx);
  *   rollout_dense 0|1      drl_rollout_batch: full passes only
  *   vae_s 0|1              wide windows: 1 default, the software-pipelined kernel (vae_wide16s_kernel) wherever one of its
  *                          workgroups fits a CU's LDS; 0: vae_wide16_kernel instead (same bits; tests, A/B)
- *   h128_split 0|1         lstm_h128p_kernel: a last round of 64-window tiles that is at most half full runs as 32-window
- *                          tiles in a second launch (default 1; same bits, tested)
+ *   h128_split 0|1         lstm_h128i2_kernel / lstm_h128p_kernel: a last round of 64-window tiles that is at most half
+ *                          full runs as 32-window tiles in a second launch (default 1; same bits, tested)
  *   vae_pp 0|1|2           wide windows: the ping-pong kernel (vae_wide16pp_kernel; same bits, measured slower):
  *                          never (default) | from a full round of tile pairs | always
  * Unknown names: DRL_ERR_ARG. */

@@ -754,3 +754,25 @@ def test_h128p_last_round_as_half_tiles_is_bit_identical(scorer, mode, S):
         assert scorer.lstm_kernels == ["xproj_kernel<8>", "lstm_h128p_kernel<2>"], scorer.lstm_kernels
     for k in ("q", "action", "margin"):
         assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
+
+
+def test_h128i2_last_round_as_half_tiles_is_bit_identical(scorer):
+    """The univariate persistent kernel: 256 workgroups walk 64-window tiles; a last round that is at most half full runs
+    as 32-window tiles in a second launch (lstm_h128i2_kernel<1>).  Same bits as the one-launch form on a ragged batch
+    (split point inside a series; too-short and empty series around it), with the flag quirk and device MinMax."""
+    rng = np.random.default_rng(5151)
+    Wn = 25
+    lens = [Wn - 3, Wn + 64 * 100 + 11, 0, Wn + 2, Wn + 64 * 170 + 40, Wn + 64 * 25 + 63, 7]      # 256 + 42 tiles of 64
+    x = rng.random(sum(lens)).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n_seg = len(lens)
+    scorer.set_lstm(synth_lstm(rng, 2, 128))
+    kw = dict(vae_lag=1, flag_mode="quirk", want=("q", "action", "margin"),
+              in_scale=rng.uniform(0.5, 2.0, n_seg).astype(np.float32), in_offset=rng.uniform(-0.5, 0.5, n_seg).astype(np.float32))
+    got = scorer.score(x, Wn, off, **kw)
+    assert scorer.lstm_kernels == ["lstm_h128i2_kernel<2>", "lstm_h128i2_kernel<1>"], scorer.lstm_kernels
+    with scorer.knob("h128_split", 0, restore=1):
+        ref = scorer.score(x, Wn, off, **kw)
+        assert scorer.lstm_kernels == ["lstm_h128i2_kernel<2>"], scorer.lstm_kernels
+    for k in ("q", "action", "margin"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k
