@@ -47,6 +47,8 @@ template <bool SCALED, int VWS_RING, int NT>
 __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Args b, int xr_floats) {
     static_assert(VWS_RING == 2 || VWS_RING == 3, "ring of two or three slabs");
     static_assert(NT == 4 || NT == 8, "four or eight row tiles");
+    constexpr int SPM = 8 / NT;                             // side operations per MFMA slot of the slab loops
+    constexpr int HT = NT / 2;                              // last layer: input tiles per half
     extern __shared__ __attribute__((aligned(16))) float vws_smem[];
     float* wt = vws_smem;                                   // [VWS_RING][VW16_SLAB]
     float* side = vws_smem + VWS_RING * VW16_SLAB;          // [VWS_RING][VW16_SIDE]
@@ -187,15 +189,19 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             __builtin_amdgcn_sched_barrier(0);
             // first half; behind its MFMAs: the second-half fragments of this slab, the inputs and scaler entries of
             // the next one (their registers are free: this slab's inputs are transformed already)
+            // (SPM side operations behind each of the half's 4 NT MFMAs: one for eight row tiles, two for four)
+            auto side_a = [&](int n) __attribute__((always_inline)) {
+                if (n < 8) { if (n < NT) av[n * 2 + 1] = *reinterpret_cast<const f32x4*>(wb + (n * 2 + 1) * 256); }
+                else if (n < 16) xv[n - 8] = xt[4 * (n - 8)];
+                else if (n < 24) { if (SCALED) sc[(n - 16) >> 1][(n - 16) & 1] = *reinterpret_cast<const f32x4*>(sb + ((n - 16) >> 1) * 32 + ((n - 16) & 1) * 4); }
+            };
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int T = 0; T < 8; ++T) {
-                    if (T < NT) cur[T] = mfma16x4(av[T * 2][ks], bv[ks], cur[T]);
-                    const int n = ks * 8 + T;
-                    if (n < 8) { if (n < NT) av[n * 2 + 1] = *reinterpret_cast<const f32x4*>(wb + (n * 2 + 1) * 256); }
-                    else if (n < 16) xv[n - 8] = xt[4 * (n - 8)];
-                    else if (n < 24) { if (SCALED) sc[(n - 16) >> 1][(n - 16) & 1] = *reinterpret_cast<const f32x4*>(sb + ((n - 16) >> 1) * 32 + ((n - 16) & 1) * 4); }
+                for (int T = 0; T < NT; ++T) {
+                    cur[T] = mfma16x4(av[T * 2][ks], bv[ks], cur[T]);
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) side_a((ks * NT + T) * SPM + j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             VWS_STAMP(1);
@@ -204,18 +210,21 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             // second half; behind its MFMAs: the first-half fragments of the next slab (into the registers the first
             // half has left), slab it+2 into the ring (the buffer slab it-1 has left), slab it+3 requested, and the
             // next slab's inputs transformed, each into its register as soon as this slab has used it
+            auto side_b = [&](int n) __attribute__((always_inline)) {
+                if (n < 8) { if (n < NT) av[n * 2] = *reinterpret_cast<const f32x4*>(wn + (n * 2) * 256); }
+                else if (n < 12) *reinterpret_cast<f32x4*>(stp + (n - 8) * 1024) = stg[n - 8];
+                else if (n == 12) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
+                else if (n == 13) { vw16_stage_load(stg, wp, voff); if (side_thr) side_next = sp[0]; }
+                else if (n == 16 || n == 17) transform(n - 16);     // (ks 0..3: the first half's)
+                else if (n == 18) transform(2);             // (ks 4, 5: used by MFMAs 0..2 NT - 1 of this half, behind us here)
+            };
 #pragma unroll
             for (int ks = 4; ks < 8; ++ks)
 #pragma unroll
-                for (int T = 0; T < 8; ++T) {
-                    if (T < NT) cur[T] = mfma16x4(av[T * 2 + 1][ks & 3], bv[ks], cur[T]);
-                    const int n = (ks - 4) * 8 + T;
-                    if (n < 8) { if (n < NT) av[n * 2] = *reinterpret_cast<const f32x4*>(wn + (n * 2) * 256); }
-                    else if (n < 12) *reinterpret_cast<f32x4*>(stp + (n - 8) * 1024) = stg[n - 8];
-                    else if (n == 12) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
-                    else if (n == 13) { vw16_stage_load(stg, wp, voff); if (side_thr) side_next = sp[0]; }
-                    else if (n == 16 || n == 17) transform(n - 16);     // (ks 0..3: the first half's)
-                    else if (n == 18) transform(2);         // (ks 4, 5 were used by MFMAs 0..15 of this half)
+                for (int T = 0; T < NT; ++T) {
+                    cur[T] = mfma16x4(av[T * 2 + 1][ks & 3], bv[ks], cur[T]);
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) side_b(((ks - 4) * NT + T) * SPM + j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             transform(3);                                   // (ks 6, 7: by MFMAs 16..31)
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
                     for (int tb = 0; tb < 4; ++tb) sc[T2][tb] = *reinterpret_cast<const f32x4*>(sb + tb * 32 + 16 * T2);
             }
 #pragma unroll
-            for (int Tin = 0; Tin < 4; ++Tin) {
+            for (int Tin = 0; Tin < HT; ++Tin) {
                 av[Tin] = *reinterpret_cast<const f32x4*>(wl + Tin * 256);
                 av[8 + Tin] = *reinterpret_cast<const f32x4*>(wl + (8 + Tin) * 256);
             }
@@ -384,42 +393,57 @@ __global__ __launch_bounds__(256, 2) void vae_wide16s_kernel(VaeArgs a, Vae16Arg
             __builtin_amdgcn_sched_barrier(0);
             // first half (input tiles 0..3); behind its MFMAs: the second-half fragments of this slab, the biases,
             // inputs and scaler entries of the next one
+            // (input tiles 0..HT-1 in this half, HT..NT-1 in the second; SPM side operations behind each MFMA)
+            auto side_c0 = [&](int n) __attribute__((always_inline)) {
+                if (n < 4) { if (n < HT) av[HT + n] = *reinterpret_cast<const f32x4*>(wb + (HT + n) * 256); }
+                else if (n == 4) accn0 = *reinterpret_cast<const f32x4*>(sb + 128);
+                else if (n < 9) { if (SCALED) sc[0][n - 5] = *reinterpret_cast<const f32x4*>(sb + (n - 5) * 32); }
+                else if (n < 13) xv[n - 9] = xt[n - 9];
+            };
+            auto side_c1 = [&](int n) __attribute__((always_inline)) {
+                if (n < 4) { if (n < HT) av[8 + HT + n] = *reinterpret_cast<const f32x4*>(wb + (8 + HT + n) * 256); }
+                else if (n == 4) accn1 = *reinterpret_cast<const f32x4*>(sb + 128 + 16);
+                else if (n < 9) { if (SCALED) sc[1][n - 5] = *reinterpret_cast<const f32x4*>(sb + (n - 5) * 32 + 16); }
+                else if (n < 13) xv[4 + n - 9] = xt[16 + n - 9];
+            };
 #pragma unroll
-            for (int Tin = 0; Tin < 4; ++Tin)
+            for (int Tin = 0; Tin < HT; ++Tin)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = Tin * 4 + r;
                     acc0 = mfma16x4(av[Tin][r], cur[Tin][r], acc0);
-                    if (n < 4) { if (4 + n < NT) av[4 + n] = *reinterpret_cast<const f32x4*>(wb + (4 + n) * 256); }
-                    else if (n == 4) accn0 = *reinterpret_cast<const f32x4*>(sb + 128);
-                    else if (n < 9) { if (SCALED) sc[0][n - 5] = *reinterpret_cast<const f32x4*>(sb + (n - 5) * 32); }
-                    else if (n < 13) xv[n - 9] = xt[n - 9];
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) side_c0((Tin * 4 + r) * SPM + j);
                     __builtin_amdgcn_sched_barrier(0);
                     acc1 = mfma16x4(av[8 + Tin][r], cur[Tin][r], acc1);
-                    if (n < 4) { if (4 + n < NT) av[12 + n] = *reinterpret_cast<const f32x4*>(wb + (12 + n) * 256); }
-                    else if (n == 4) accn1 = *reinterpret_cast<const f32x4*>(sb + 128 + 16);
-                    else if (n < 9) { if (SCALED) sc[1][n - 5] = *reinterpret_cast<const f32x4*>(sb + (n - 5) * 32 + 16); }
-                    else if (n < 13) xv[4 + n - 9] = xt[16 + n - 9];
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) side_c1((Tin * 4 + r) * SPM + j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             if (VWS_RING == 2) __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             // second half (input tiles 4..7); behind its MFMAs: the first-half fragments of the next slab, slab ot+2
             // into the ring, slab ot+3 requested
+            auto side_d0 = [&](int n) __attribute__((always_inline)) {
+                if (n < 4) { if (n < HT) av[n] = *reinterpret_cast<const f32x4*>(wn + n * 256); }
+                else if (n < 8) *reinterpret_cast<f32x4*>(stp + (n - 4) * 1024) = stg[n - 4];
+                else if (n == 8) { vw16_stage_load(stg, wp, voff); }
+            };
+            auto side_d1 = [&](int n) __attribute__((always_inline)) {
+                if (n < 4) { if (n < HT) av[8 + n] = *reinterpret_cast<const f32x4*>(wn + (8 + n) * 256); }
+                else if (n == 4) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
+                else if (n == 8) { if (side_thr) side_next = sp[0]; }
+            };
 #pragma unroll
-            for (int Tin = 4; Tin < 8; ++Tin)
+            for (int Tin = HT; Tin < NT; ++Tin)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = (Tin - 4) * 4 + r;
-                    if (Tin < NT) acc0 = mfma16x4(av[Tin][r], cur[Tin][r], acc0);
-                    if (n < 4) av[n] = *reinterpret_cast<const f32x4*>(wn + n * 256);
-                    else if (n < 8) *reinterpret_cast<f32x4*>(stp + (n - 4) * 1024) = stg[n - 4];
-                    else if (n == 8) { vw16_stage_load(stg, wp, voff); }
+                    acc0 = mfma16x4(av[Tin][r], cur[Tin][r], acc0);
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) side_d0(((Tin - HT) * 4 + r) * SPM + j);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (Tin < NT) acc1 = mfma16x4(av[8 + Tin][r], cur[Tin][r], acc1);
-                    if (n < 4) av[8 + n] = *reinterpret_cast<const f32x4*>(wn + (8 + n) * 256);
-                    else if (n == 4) { if (side_thr) sdw[rp * VW16_SIDE] = side_next; }
-                    else if (n == 8) { if (side_thr) side_next = sp[0]; }
+                    acc1 = mfma16x4(av[8 + Tin][r], cur[Tin][r], acc1);
+#pragma unroll
+                    for (int j = 0; j < SPM; ++j) side_d1(((Tin - HT) * 4 + r) * SPM + j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             wp += VW16_SLAB;
